@@ -1,0 +1,155 @@
+"""Build + load the gfx950 shared library and expose typed ctypes entry points.
+
+The library is plain C-ABI (include/caiman_rnnt.h): device pointers, extents, a dtype
+tag and a hipStream_t.  torch is used here only to obtain `data_ptr()` and the current
+stream — plumbing, not compute.  If the library cannot be loaded every op raises
+(`MissingNativeLibrary`); there is deliberately no fallback path.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcaiman_rnnt.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "caiman_rnnt.h")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+
+
+class MissingNativeLibrary(RuntimeError):
+    pass
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every .hip translation unit for gfx950 and link libcaiman_rnnt.so in-tree."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, procs = [], []
+    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) + [HEADER])
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > hdr_t):
+            continue
+        cmd = [HIPCC, *HIP_FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+P = ctypes.c_void_p
+I64 = ctypes.c_int64
+I32 = ctypes.c_int
+U32 = ctypes.c_uint32
+F64 = ctypes.c_double
+
+_SIGS = {
+    "caiman_abi_version": ([], ctypes.c_int),
+    "caiman_last_error": ([], ctypes.c_char_p),
+    "caiman_built_for_gfx950": ([], ctypes.c_int),
+    "caiman_logsumexp": ([P, I64, I64, I64, I32, P, I32, U32, P], ctypes.c_int),
+    "caiman_transducer_loss_forward": (
+        [P, P, P, P, P, P, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32, P, P, P, P],
+        ctypes.c_int),
+    "caiman_transducer_loss_backward": (
+        [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
+         P, P], ctypes.c_int),
+    "caiman_lstm_fused_fwd": ([P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
+    "caiman_lstm_fused_bwd": ([P, P, P, P, I64, I64, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
+}
+
+
+def exported_symbols():
+    """Names declared in include/caiman_rnnt.h (used by the CPU-side ABI test)."""
+    import re
+
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(caiman_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MissingNativeLibrary(
+                f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "There is no CPU/PyTorch fallback for the RNN-T kernels.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise MissingNativeLibrary(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (argtypes, restype) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(lib().caiman_last_error().decode())
+
+
+_DTYPE_TAG = {torch.float64: 0, torch.float32: 1, torch.float16: 2, torch.bfloat16: 3}
+
+
+def dtype_tag(dtype) -> int:
+    try:
+        return _DTYPE_TAG[dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {dtype}; expected one of {list(_DTYPE_TAG)}")
+
+
+def acc_dtype(dtype):
+    """at::acc_type<T, true>: double for double, float otherwise."""
+    return torch.float64 if dtype == torch.float64 else torch.float32
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check_input(t, name):
+    """MYRTLE_CHECK_INPUT (training/lib/csrc/myrtle/utility.hpp:52-72)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(
+            f"{name} must be contiguous but got shape{list(t.shape)} and strides {list(t.stride())} "
+            f"such that numel is {t.numel()}")

@@ -1,0 +1,28 @@
+// Library identity + error plumbing for the C-ABI (include/caiman_rnnt.h).
+#include "common.h"
+
+namespace caiman {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return CAIMAN_ERR_LAUNCH;
+  }
+  return CAIMAN_OK;
+}
+
+}  // namespace caiman
+
+extern "C" int caiman_abi_version(void) { return 1; }
+extern "C" const char* caiman_last_error(void) { return caiman::g_err; }
+extern "C" int caiman_built_for_gfx950(void) { return 1; }

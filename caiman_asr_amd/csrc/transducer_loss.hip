@@ -1,0 +1,411 @@
+// RNN-T transducer loss (alpha/beta lattice + fused log-softmax backward) for gfx950.
+//
+// Arithmetic contract: training/lib/csrc/transducer_loss.cu
+//   :46-62   log_sum_exp, frac_penalty, sub_or_nan
+//   :101-264 forward (alpha / beta anti-diagonal recursion, loss = -beta[0,0])
+//   :297-394 fused backward (softmax backward + lattice gradient, delay / EOS / star terms)
+// restated in SURVEY.md Appendix A.3.  The kernels below are a new design:
+//   forward : one workgroup per (direction, utterance); lane <-> u; the previous
+//             anti-diagonal lives in registers + a double-buffered LDS line (the
+//             reference round-trips alpha/beta through global memory every step);
+//             the two gathered logits + denominators of the NEXT diagonals are
+//             prefetched PF steps ahead so the dependent chain is ALU + LDS only.
+//   backward: one wave64 per lattice cell row (V logits); 16-byte coalesced
+//             loads/stores, no LDS, no barrier; launch covers exactly the packed
+//             rows (the reference launches a (Umax+1, Tmax, B) grid and early-outs).
+#include "common.h"
+
+namespace caiman {
+namespace {
+
+template <typename A>
+__device__ __forceinline__ A lse2(A a, A b) {
+  // transducer_loss.cu:46-52
+  return (a >= b) ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
+}
+template <typename A>
+__device__ __forceinline__ A frac_penalty(A lam, A t, A T) {
+  return lam * ((T - 1) / 2 - t);  // transducer_loss.cu:54-57
+}
+template <typename A>
+__device__ __forceinline__ A sub_or_nan(A num, A den) {
+  return isfinite(den) ? num - den : static_cast<A>(NAN);  // transducer_loss.cu:59-62
+}
+
+struct LossParams {
+  const int32_t* label;
+  const int32_t* f_len;
+  const int32_t* y_len;
+  const int64_t* batch_offset;
+  int64_t max_flen, max_glen, V, blank, eos_idx, star_idx;
+  double dp_lam, eos_lam, star_lam;
+  int packed;
+  int batch;
+};
+
+constexpr int kPF = 4;  // prefetch distance (anti-diagonals) of the forward kernel
+
+// ---------------------------------------------------------------------------
+// forward: grid (2, B); blockIdx.x = 0 -> alpha, 1 -> beta. blockDim = NT >= U'.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
+                                                        const acc_t<T>* __restrict__ denom,
+                                                        LossParams p, acc_t<T>* __restrict__ alpha,
+                                                        acc_t<T>* __restrict__ beta,
+                                                        acc_t<T>* __restrict__ loss) {
+  using A = acc_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  A* line = reinterpret_cast<A*>(smem_raw);  // [2][blockDim.x + 2]
+
+  const int b = blockIdx.y;
+  const int u = threadIdx.x;
+  const int NT = blockDim.x;
+  const int64_t Tn = p.f_len[b];
+  const int64_t Un = p.y_len[b] + 1;  // U' = labels + SOS
+  const int32_t* lab = p.label + (int64_t)b * (p.max_glen - 1);
+  const int64_t off = p.packed ? (b == 0 ? 0 : p.batch_offset[b - 1]) : (int64_t)b * p.max_flen * p.max_glen;
+  const int64_t stride = p.packed ? Un : p.max_glen;
+  const T* xb = x + off * p.V;
+  const A* db = denom + off;
+  const A dp_lam = (A)p.dp_lam, eos_lam = (A)p.eos_lam, star_lam = (A)p.star_lam;
+  const A Tf = (A)Tn;
+
+  const bool active = u < Un;
+  // per-lane label facts
+  const int32_t lab_u = (active && u < Un - 1) ? lab[u] : -3;     // label emitted when leaving (.,u) upward
+  const int32_t lab_um1 = (active && u > 0) ? lab[u - 1] : -3;    // label that brought us to row u
+  const bool row_is_star = (u > 0) && (lab_um1 == p.star_idx);    // null(t,u) = star_lam
+  A* buf0 = line;
+  A* buf1 = line + (NT + 2);
+
+  if (blockIdx.x == 0) {
+    // ------------------------------ alpha ----------------------------------
+    A* my_alpha = alpha + (int64_t)b * p.max_flen * p.max_glen;
+    // cell (t,u) on diagonal s = t + u needs null(t-1,u) and emit(t,u-1).
+    // ring slot k holds the raw operands for diagonal s with (s % kPF == k).
+    A xn[kPF], dn[kPF], xe[kPF], de[kPF];
+    const bool emit_is_star = (u > 0) && (lab_um1 == p.star_idx);  // emit(t,u-1) with label[u-1]==star
+    auto issue = [&](int64_t s, int k) {
+      const int64_t t = s - u;
+      xn[k] = 0; dn[k] = 0; xe[k] = 0; de[k] = 0;
+      if (active && t >= 0 && t < Tn) {
+        if (t > 0) {
+          const int64_t c = (t - 1) * stride + u;
+          xn[k] = static_cast<A>(xb[c * p.V + p.blank]);
+          dn[k] = db[c];
+        }
+        if (u > 0) {
+          const int64_t c = t * stride + (u - 1);
+          de[k] = db[c];
+          if (!emit_is_star) xe[k] = static_cast<A>(xb[c * p.V + lab_um1]);
+        }
+      }
+    };
+    const int64_t nsteps = Tn + Un - 1;  // diagonals 0 .. nsteps-1
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) issue(1 + k, (1 + k) % kPF);
+
+    A mine = 0;  // alpha(t,u) of the previous diagonal for this lane (t-1,u)
+    if (u == 0) my_alpha[0] = 0;
+    buf0[u + 1] = (u == 0) ? (A)0 : (A)0;  // diagonal 0: only (0,0) is valid
+    __syncthreads();
+
+    for (int64_t s0 = 1; s0 < nsteps; s0 += kPF) {
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) {
+        const int64_t s = s0 + k;
+        if (s >= nsteps) break;
+        const int slot = (1 + k) % kPF;  // s % kPF because s0 ≡ 1 (mod kPF)
+        A* prev = ((s - 1) & 1) ? buf1 : buf0;
+        A* cur = (s & 1) ? buf1 : buf0;
+        const int64_t t = s - u;
+        const bool valid = active && t >= 0 && t < Tn;
+        A val = mine;
+        if (valid) {
+          const A left = prev[u];  // alpha(t, u-1) (slot u holds lane u-1's value)
+          A a_null = 0, a_emit = 0;
+          if (t > 0) {
+            const A lp = sub_or_nan<A>(xn[slot], dn[slot]);
+            const A nul = (u == 0) ? lp : (row_is_star ? star_lam : lp);
+            a_null = mine + nul;
+          }
+          if (u > 0) {
+            const A dp = frac_penalty<A>(dp_lam, (A)t, Tf);
+            A em;
+            if (emit_is_star) {
+              em = dp;
+            } else {
+              em = sub_or_nan<A>(xe[slot], de[slot]) + dp;
+              if (lab_um1 == p.eos_idx) em += frac_penalty<A>(eos_lam, (A)t, Tf);
+            }
+            a_emit = left + em;
+          }
+          val = (u == 0) ? a_null : (t == 0 ? a_emit : lse2<A>(a_null, a_emit));
+          my_alpha[t * p.max_glen + u] = val;
+        }
+        mine = val;
+        cur[u + 1] = val;
+        issue(s + kPF, slot);
+        __syncthreads();
+      }
+    }
+  } else {
+    // ------------------------------ beta -----------------------------------
+    A* my_beta = beta + (int64_t)b * p.max_flen * p.max_glen;
+    // cell (t,u) on diagonal s = t + u needs null(t,u) and emit(t,u) (same cell).
+    A xn[kPF], xe[kPF], dd[kPF];
+    const bool emit_is_star = active && (u < Un - 1) && (lab_u == p.star_idx);
+    auto issue = [&](int64_t s, int k) {
+      const int64_t t = s - u;
+      xn[k] = 0; xe[k] = 0; dd[k] = 0;
+      if (active && s >= 0 && t >= 0 && t < Tn) {
+        const int64_t c = t * stride + u;
+        dd[k] = db[c];
+        xn[k] = static_cast<A>(xb[c * p.V + p.blank]);
+        if (u < Un - 1 && !emit_is_star) xe[k] = static_cast<A>(xb[c * p.V + lab_u]);
+      }
+    };
+    const int64_t top = Tn + Un - 2;  // diagonal of the terminal cell
+    // Walk diagonals top, top-1, ..., 0. Use j = top - s as the ascending counter
+    // so ring slots are static: slot(j) = j % kPF.
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) issue(top - k, k);
+
+    A mine = 0;  // beta(t+1, u) for this lane
+    for (int64_t j0 = 0; j0 <= top; j0 += kPF) {
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) {
+        const int64_t j = j0 + k;
+        if (j > top) break;
+        const int64_t s = top - j;
+        A* prev = ((j + 1) & 1) ? buf1 : buf0;  // written at step j-1
+        A* cur = (j & 1) ? buf1 : buf0;
+        const int64_t t = s - u;
+        const bool valid = active && t >= 0 && t < Tn;
+        A val = mine;
+        if (valid) {
+          const A lp_blank = sub_or_nan<A>(xn[k], dd[k]);
+          const A nul = (u == 0) ? lp_blank : (row_is_star ? star_lam : lp_blank);
+          if (t == Tn - 1 && u == Un - 1) {
+            val = nul;  // transducer_loss.cu:228
+          } else {
+            A em = 0;
+            if (u < Un - 1) {
+              const A dp = frac_penalty<A>(dp_lam, (A)t, Tf);
+              if (emit_is_star) {
+                em = dp;
+              } else {
+                em = sub_or_nan<A>(xe[k], dd[k]) + dp;
+                if (lab_u == p.eos_idx) em += frac_penalty<A>(eos_lam, (A)t, Tf);
+              }
+            }
+            if (u == Un - 1) {
+              val = mine + nul;
+            } else {
+              const A up = prev[u + 2];  // beta(t, u+1) from lane u+1, previous step
+              val = (t == Tn - 1) ? up + em : lse2<A>(mine + nul, up + em);
+            }
+          }
+          my_beta[t * p.max_glen + u] = val;
+        }
+        mine = val;
+        cur[u + 1] = val;
+        issue(s - kPF, k);
+        __syncthreads();
+      }
+    }
+    if (u == 0) loss[b] = -mine;  // lane 0 finishes on cell (0,0): transducer_loss.cu:260-262
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward: one wave per [*, V] row.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) vecT {
+  T v[VEC];
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(
+    const T* __restrict__ x, const acc_t<T>* __restrict__ denom,
+    const acc_t<T>* __restrict__ loss_grad, const acc_t<T>* __restrict__ alpha,
+    const acc_t<T>* __restrict__ beta, LossParams p, int64_t total_rows, T* __restrict__ x_grad) {
+  using A = acc_t<T>;
+  using Vt = vecT<T, VEC>;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  if (row >= total_rows) return;
+
+  // ---- locate (b, t, u) for this row -------------------------------------------
+  int b;
+  int64_t local;
+  int64_t Un_stride;
+  if (p.packed) {
+    // smallest b with batch_offset[b] > row (batch_offset is an inclusive cumsum)
+    int lo = 0, hi = p.batch - 1;  // the last utterance needs no comparison
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (p.batch_offset[mid] > row) hi = mid; else lo = mid + 1;
+    }
+    b = lo;
+    local = row - (b == 0 ? 0 : p.batch_offset[b - 1]);
+    Un_stride = p.y_len[b] + 1;
+  } else {
+    const int64_t per = p.max_flen * p.max_glen;
+    b = (int)(row / per);
+    local = row - (int64_t)b * per;
+    Un_stride = p.max_glen;
+  }
+  const int64_t Tn = p.f_len[b];
+  const int64_t Un = p.y_len[b] + 1;
+  const int64_t t = local / Un_stride;
+  const int64_t u = local - t * Un_stride;
+  T* gx = x_grad + row * p.V;
+  const int64_t nfull = p.V / VEC;
+
+  if (t >= Tn || u >= Un) {
+    // padded layout: zero the don't-care region (transducer_loss.cu:388-393)
+    Vt z;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) z.v[j] = static_cast<T>(0);
+    for (int64_t c = lane; c < nfull; c += kWave) *reinterpret_cast<Vt*>(gx + c * VEC) = z;
+    for (int64_t h = nfull * VEC + lane; h < p.V; h += kWave) gx[h] = static_cast<T>(0);
+    return;
+  }
+
+  const T* rx = x + row * p.V;
+  const A* my_alpha = alpha + (int64_t)b * p.max_flen * p.max_glen;
+  const A* my_beta = beta + (int64_t)b * p.max_flen * p.max_glen;
+  const int32_t* lab = p.label + (int64_t)b * (p.max_glen - 1);
+  const A dp_lam = (A)p.dp_lam, eos_lam = (A)p.eos_lam, star_lam = (A)p.star_lam;
+  const A Tf = (A)Tn;
+
+  // wave-uniform scalars (every lane loads the same addresses: broadcast)
+  const A den = denom[row];
+  const bool den_ok = isfinite(den);
+  const A common = log(loss_grad[b]) + my_alpha[t * p.max_glen + u] - my_beta[0];
+  const A beta_TU = my_beta[t * p.max_glen + u];
+  const int32_t labU = (u == 0) ? -1 : lab[u - 1];
+  const bool not_top = (u != Un - 1);
+  const bool last_t = (t == Tn - 1);
+  A beta_TUp1 = 0, beta_Tp1U = 0;
+  int32_t labUp1 = -4;
+  if (!last_t) beta_Tp1U = my_beta[(t + 1) * p.max_glen + u];
+  if (not_top) {
+    beta_TUp1 = my_beta[t * p.max_glen + u + 1] + frac_penalty<A>(dp_lam, (A)t, Tf);
+    labUp1 = lab[u];
+    if (labUp1 == p.eos_idx) beta_TUp1 += frac_penalty<A>(eos_lam, (A)t, Tf);
+  }
+  const bool up_all = not_top && (labUp1 == p.star_idx);
+  const bool right_all = (labU == p.star_idx);
+  const A star_pen = right_all ? star_lam : (A)0;
+  // right contribution exists for the terminal cell or any non-last frame
+  const bool right_term = last_t && !not_top;
+  const bool right_any = right_term || !last_t;
+  const A right_add = right_term ? star_pen : beta_Tp1U + star_pen;
+
+  auto one = [&](A xv, int64_t h) -> A {
+    const A grad = common + (den_ok ? xv - den : static_cast<A>(NAN));
+    A g = exp(grad + beta_TU);
+    if (not_top && (up_all || h == labUp1)) g -= exp(grad + beta_TUp1);
+    if (right_any && (right_all || h == p.blank)) g -= exp(grad + right_add);
+    return g;
+  };
+
+  for (int64_t c = lane; c < nfull; c += kWave) {
+    const Vt v = *reinterpret_cast<const Vt*>(rx + c * VEC);
+    Vt o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = static_cast<T>(one(static_cast<A>(v.v[j]), c * VEC + j));
+    *reinterpret_cast<Vt*>(gx + c * VEC) = o;
+  }
+  for (int64_t h = nfull * VEC + lane; h < p.V; h += kWave) gx[h] = static_cast<T>(one(static_cast<A>(rx[h]), h));
+}
+
+int check_common(int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t V, int64_t blank,
+                 int64_t eos_idx, int64_t star_idx) {
+  CAIMAN_CHECK(batch >= 1 && max_f_len >= 1 && max_g_len >= 1 && V >= 1, "transducer_loss: bad extents");
+  // transducer_loss.cu:429-448
+  CAIMAN_CHECK(blank >= 0 && blank < V, "Expected blank index to be in the range of 0 to %lld, but got %lld",
+               (long long)(V - 1), (long long)blank);
+  CAIMAN_CHECK(eos_idx < V, "Expected eos index to be less than %lld, but got %lld", (long long)(V - 1),
+               (long long)eos_idx);
+  CAIMAN_CHECK(star_idx < V, "Expected star index to be less than %lld, but got %lld", (long long)(V - 1),
+               (long long)star_idx);
+  return CAIMAN_OK;
+}
+
+}  // namespace
+}  // namespace caiman
+
+extern "C" int caiman_transducer_loss_forward(
+    const void* x, const void* denom, const int32_t* label, const int32_t* f_len, const int32_t* y_len,
+    const int64_t* batch_offset, int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t dict_size,
+    double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx, double star_lam, int64_t star_idx,
+    int packed, int dtype, void* alpha, void* beta, void* loss, caiman_stream_t stream) {
+  using namespace caiman;
+  if (int e = check_common(batch, max_f_len, max_g_len, dict_size, blank_idx, eos_idx, star_idx)) return e;
+  CAIMAN_CHECK(x && denom && label && f_len && y_len && alpha && beta && loss, "transducer_loss_forward: null pointer");
+  CAIMAN_CHECK(!packed || batch_offset, "transducer_loss_forward: packed input needs batch_offset");
+  CAIMAN_CHECK(max_g_len <= 1024, "transducer_loss_forward: max_g_len %lld > 1024 not supported",
+               (long long)max_g_len);
+  CAIMAN_CHECK(batch <= 65535, "transducer_loss_forward: batch too large for one launch");
+  LossParams p{label, f_len, y_len, batch_offset, max_f_len, max_g_len, dict_size, blank_idx,
+               eos_idx, star_idx, dp_lam, eos_lam, star_lam, packed, (int)batch};
+  const int nt = (int)(((max_g_len + kWave - 1) / kWave) * kWave);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return CAIMAN_DISPATCH(dtype, "transducer_loss_forward", [&]() -> int {
+    using A = acc_t<scalar_t>;
+    const size_t shm = 2 * (size_t)(nt + 2) * sizeof(A);
+    hipLaunchKernelGGL((loss_fwd_kernel<scalar_t>), dim3(2, (unsigned)batch), dim3(nt), shm, s,
+                       static_cast<const scalar_t*>(x), static_cast<const A*>(denom), p,
+                       static_cast<A*>(alpha), static_cast<A*>(beta), static_cast<A*>(loss));
+    return check_launch("caiman_transducer_loss_forward");
+  });
+}
+
+extern "C" int caiman_transducer_loss_backward(
+    const void* x, const void* denom, const void* loss_grad, const void* alpha, const void* beta,
+    const int32_t* f_len, const int32_t* y_len, const int32_t* label, const int64_t* batch_offset,
+    int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t dict_size, int64_t total_rows,
+    double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx, double star_lam, int64_t star_idx,
+    int packed, int dtype, void* x_grad, caiman_stream_t stream) {
+  using namespace caiman;
+  if (int e = check_common(batch, max_f_len, max_g_len, dict_size, blank_idx, eos_idx, star_idx)) return e;
+  CAIMAN_CHECK(x && denom && loss_grad && alpha && beta && label && f_len && y_len && x_grad,
+               "transducer_loss_backward: null pointer");
+  CAIMAN_CHECK(!packed || batch_offset, "transducer_loss_backward: packed input needs batch_offset");
+  CAIMAN_CHECK(total_rows >= 0, "transducer_loss_backward: negative row count");
+  CAIMAN_CHECK(packed || total_rows == batch * max_f_len * max_g_len,
+               "transducer_loss_backward: padded input must have B*T*U rows");
+  CAIMAN_CHECK(batch <= 65535, "transducer_loss_backward: batch too large for one launch");
+  if (total_rows == 0) return CAIMAN_OK;
+  LossParams p{label, f_len, y_len, batch_offset, max_f_len, max_g_len, dict_size, blank_idx,
+               eos_idx, star_idx, dp_lam, eos_lam, star_lam, packed, (int)batch};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int kRowsPerBlock = 4;
+  const int64_t nblk = (total_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  CAIMAN_CHECK(nblk < ((int64_t)1 << 31), "transducer_loss_backward: too many rows for one launch");
+  return CAIMAN_DISPATCH(dtype, "transducer_loss_backward", [&]() -> int {
+    using A = acc_t<scalar_t>;
+    constexpr int VEC = 16 / sizeof(scalar_t);
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(x_grad) % 16 == 0) &&
+                         ((dict_size * (int64_t)sizeof(scalar_t)) % 16 == 0);
+    const dim3 grid((unsigned)nblk);
+    auto xs = static_cast<const scalar_t*>(x);
+    auto gs = static_cast<scalar_t*>(x_grad);
+    if (aligned) {
+      hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, VEC>), grid, dim3(256), 0, s, xs,
+                         static_cast<const A*>(denom), static_cast<const A*>(loss_grad),
+                         static_cast<const A*>(alpha), static_cast<const A*>(beta), p, total_rows, gs);
+    } else {
+      hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, 1>), grid, dim3(256), 0, s, xs,
+                         static_cast<const A*>(denom), static_cast<const A*>(loss_grad),
+                         static_cast<const A*>(alpha), static_cast<const A*>(beta), p, total_rows, gs);
+    }
+    return check_launch("caiman_transducer_loss_backward");
+  });
+}

@@ -1,0 +1,68 @@
+"""rnnt_ext.cuda.lstm — training/lib/csrc/lstm.cu:411-456 (pybind signatures),
+:353-405 (checks + dispatch).  Ops mutate caller-allocated tensors in place."""
+import torch
+
+from caiman_asr_amd import _lib
+
+
+def _dims(c):
+    # lstm.cu:226-228: c is [T+1, B, H] or [T+1, H]
+    if c.dim() == 3:
+        return c.size(1), c.size(2)
+    return 1, c.size(1)
+
+
+def _fwd(R, gates, c, y, hard):
+    for t, n in ((R, "R"), (gates, "gates"), (c, "c"), (y, "y")):
+        _lib.check_input(t, n)
+    if not (R.dtype == gates.dtype == c.dtype == y.dtype):
+        raise RuntimeError("R, gates, c and y must share one dtype")
+    T = gates.size(0)
+    B, H = _dims(c)
+    if R.shape != (4 * H, H) or gates.numel() != T * B * 4 * H or c.size(0) != T + 1 or y.shape != c.shape:
+        raise RuntimeError(f"inconsistent LSTM shapes R{list(R.shape)} gates{list(gates.shape)} "
+                           f"c{list(c.shape)} y{list(y.shape)}")
+    _lib.check(_lib.lib().caiman_lstm_fused_fwd(
+        _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(y), T, B, H, _lib.dtype_tag(gates.dtype),
+        int(hard), _lib.stream()))
+
+
+def _bwd(R, gates, c, delta, dG, hard):
+    if not delta.is_cuda:
+        raise RuntimeError("delta must be a CUDA tensor")
+    for t, n in ((R, "R"), (gates, "gates"), (c, "c"), (dG, "dG")):
+        _lib.check_input(t, n)
+    T = delta.size(0)
+    B, H = _dims(c)
+    if T == 0:
+        return
+    d = delta if delta.dim() == 3 else delta.unsqueeze(1)
+    if d.stride(2) != 1 and H > 1:
+        d = d.contiguous()  # the reference always copies (lstm.cu:394-396)
+    dC = torch.empty((B, H), dtype=_lib.acc_dtype(gates.dtype), device=gates.device)
+    use_rt = gates.dtype in (torch.float16, torch.bfloat16) and H % 64 == 0
+    Rt = torch.empty((H, 4 * H), dtype=R.dtype, device=R.device) if use_rt else None
+    _lib.check(_lib.lib().caiman_lstm_fused_bwd(
+        _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(d), d.stride(0), d.stride(1), _lib.ptr(dG),
+        _lib.ptr(dC), _lib.ptr(Rt) if Rt is not None else None, T, B, H, _lib.dtype_tag(gates.dtype),
+        int(hard), _lib.stream()))
+
+
+def lstm_fused_fwd_soft(R, gates, c, y):
+    """Compute the LSTM forward pass with soft activation functions."""
+    _fwd(R, gates, c, y, False)
+
+
+def lstm_fused_fwd_hard(R, gates, c, y):
+    """Compute the LSTM forward pass with hard activation functions."""
+    _fwd(R, gates, c, y, True)
+
+
+def lstm_fused_bwd_soft(R, gates, c, delta, dG):
+    """Compute the LSTM backward pass with soft activation functions."""
+    _bwd(R, gates, c, delta, dG, False)
+
+
+def lstm_fused_bwd_hard(R, gates, c, delta, dG):
+    """Compute the LSTM backward pass with hard activation functions."""
+    _bwd(R, gates, c, delta, dG, True)

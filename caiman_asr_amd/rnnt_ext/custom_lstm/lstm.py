@@ -1,0 +1,171 @@
+"""rnnt_ext.custom_lstm.lstm — multi-layer LSTM with torch.nn.LSTM-compatible parameter names.
+
+Interface mirror of training/lib/src/rnnt_ext/custom_lstm/lstm.py (Function :11-144,
+Layer :161-254, CustomLSTM :257-399).  The all-timestep input GEMM and the weight-gradient
+GEMMs are plain library GEMMs (torch -> hipBLASLt); the sequential part runs in the gfx950
+kernels of csrc/lstm.hip through `rnnt_ext.cuda.lstm`.
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor as Ten
+
+import caiman_asr_amd.rnnt_ext.cuda.lstm as lstm_cu
+
+
+class Function(torch.autograd.Function):
+    """One LSTM layer over a whole sequence: returns (y[1:], c[1:]); gradients flow to x and
+    the four parameters only (no gradient to y0/c0: truncated BPTT, lstm.py:144)."""
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, lstm_fused_fwd, lstm_fused_bwd, y0: Ten, c0: Ten, x: Ten, W: Ten, R: Ten,
+                bW: Ten, bR: Ten) -> Tuple[Ten, Ten]:
+        T, B = x.shape[0], x.shape[1]
+        x_flat = x.flatten(0, 1)
+        # every timestep's x·Wᵀ + (bW + bR) in one GEMM (lstm.py:51-55); under autocast this
+        # produces the reduced-precision gate dtype that everything below inherits.
+        gates = torch.addmm(bW + bR, x_flat, W.t()).view(T, B, W.shape[0])
+        x_flat.requires_grad = x.requires_grad
+
+        shape = list(x.shape)
+        shape[-1] = W.shape[0] // 4
+        shape[0] += 1
+        y = torch.empty(shape, dtype=gates.dtype, device=x.device)
+        c = torch.empty(shape, dtype=gates.dtype, device=x.device)
+        y[0].copy_(y0)
+        c[0].copy_(c0)
+        Rp = R.type(dtype=gates.dtype)
+
+        lstm_fused_fwd(Rp, gates, c, y)
+
+        ctx.save_for_backward(W, Rp, x_flat, y[:-1].flatten(0, 1), c, gates)
+        ctx.lstm_fused_bwd = lstm_fused_bwd
+        return y[1:], c[1:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, delta: Ten, *_):
+        W, Rp, x, y, c, gates = ctx.saved_tensors
+        assert delta.dtype == Rp.dtype
+        dG = torch.empty_like(gates, memory_format=torch.contiguous_format)
+        ctx.lstm_fused_bwd(Rp, gates, c, delta, dG)
+
+        dB = dG.sum([0, 1])
+        dG2 = dG.flatten(0, 1)
+        dX = torch.matmul(dG2, W.to(dG2.dtype)).view(delta.shape[0], -1, x.shape[1]) if x.requires_grad else None
+        dW = torch.matmul(dG2.t(), x.detach().to(dG2.dtype))
+        dR = torch.matmul(dG2.t(), y)
+        return None, None, None, None, dX, dW, dR, dB.unsqueeze(0), dB.unsqueeze(0)
+
+
+class HardLayer(torch.nn.Module):
+    def forward(self, *args, **kwargs):
+        return Function.apply(lstm_cu.lstm_fused_fwd_hard, lstm_cu.lstm_fused_bwd_hard, *args, **kwargs)
+
+
+class SoftLayer(torch.nn.Module):
+    def forward(self, *args, **kwargs):
+        return Function.apply(lstm_cu.lstm_fused_fwd_soft, lstm_cu.lstm_fused_bwd_soft, *args, **kwargs)
+
+
+class Layer(torch.nn.Module):
+    """A single LSTM layer (soft or hard activations, optional recurrent-weight dropout)."""
+
+    def __init__(self, input_size: int, hidden_size: int, hard: bool = False, rw_dropout: float = 0.0,
+                 dtype=None, device=None):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.hard = hard
+        self.layer_fun = HardLayer() if hard else SoftLayer()
+        self.rw_dropout = rw_dropout
+        self.drop_fun = torch.nn.Dropout(p=rw_dropout) if rw_dropout != 0.0 else torch.nn.Identity()
+        kw = {"dtype": dtype, "device": device}
+        self.weight_ih = torch.nn.Parameter(torch.empty(4 * hidden_size, input_size, **kw))
+        self.weight_hh = torch.nn.Parameter(torch.empty(4 * hidden_size, hidden_size, **kw))
+        self.bias_ih = torch.nn.Parameter(torch.empty(4 * hidden_size, **kw))
+        self.bias_hh = torch.nn.Parameter(torch.empty(4 * hidden_size, **kw))
+        rsh = 1.0 / math.sqrt(hidden_size)
+        with torch.no_grad():
+            for param in self.parameters():
+                param.uniform_(-rsh, rsh)
+
+    def forward(self, x: Ten, state: Tuple[Ten, Ten]) -> Tuple[Ten, Ten]:
+        """x [T,B,I], state (y0, c0) each [B,H] -> (y1..yT, c1..cT)."""
+        return self.layer_fun(*state, x, self.weight_ih, self.drop_fun(self.weight_hh), self.bias_ih,
+                              self.bias_hh)
+
+    def extra_repr(self):
+        return (f"input_size={self.input_size:.>4}, hidden_size={self.hidden_size:.>4}, "
+                f"hard={self.hard}, rw_dropout={self.rw_dropout}")
+
+
+class CustomLSTM(torch.nn.Module):
+    """Partial drop-in for torch.nn.LSTM with optional hard activations; weight names match
+    torch.nn.LSTM so state_dicts / checkpoints transfer (lstm.py:323-327)."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, dropout: float = 0.0,
+                 hard: bool = False, quantize: bool = False, rw_dropout: float = 0.0, dtype=None,
+                 device=None):
+        super().__init__()
+        assert not quantize, "Cuda CustomLSTM does not support quantization"
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.bl_dropout = dropout
+        self.quantize = quantize
+        self.hard = hard
+        self.rw_dropout = rw_dropout
+        self.drop_function = torch.nn.Dropout(p=dropout) if dropout != 0.0 else torch.nn.Identity()
+        kw = dict(hidden_size=hidden_size, hard=hard, rw_dropout=rw_dropout, dtype=dtype, device=device)
+        self.layers = [Layer(input_size, **kw)]
+        self.layers.extend(Layer(hidden_size, **kw) for _ in range(num_layers - 1))
+        for i, layer in enumerate(self.layers):
+            self.register_parameter(name=f"weight_ih_l{i}", param=layer.weight_ih)
+            self.register_parameter(name=f"weight_hh_l{i}", param=layer.weight_hh)
+            self.register_parameter(name=f"bias_ih_l{i}", param=layer.bias_ih)
+            self.register_parameter(name=f"bias_hh_l{i}", param=layer.bias_hh)
+
+    def _apply(self, fn, *a, **k):
+        # `self.layers` is a plain list (as in the reference), so the Layer modules are not
+        # children; keep their Parameter objects identical to the registered ones after
+        # .to()/.cuda()/.half() replace them.
+        out = super()._apply(fn, *a, **k)
+        for i, layer in enumerate(self.layers):
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                layer._parameters[n] = self._parameters[f"{n}_l{i}"]
+        return out
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        for layer in self.layers:
+            layer.train(mode)
+        return self
+
+    def forward(self, input: Ten, state: Optional[Tuple[Ten, Ten]] = None
+                ) -> Tuple[Ten, Tuple[Ten, Ten], Tuple[Ten, Ten]]:
+        """-> (output [T,B,H], (h_n, c_n) [L,B,H], (all_h, all_c) [L,T,B,H])."""
+        h_fl, c_fl, all_h_fl, all_c_fl = [], [], [], []
+        x = None
+        for i, layer in enumerate(self.layers):
+            layer_input = input if i == 0 else self.drop_function(x)
+            if state is None:
+                shape = list(input.shape[1:])
+                shape[-1] = self.hidden_size
+                h_0 = torch.zeros(shape, device=input.device, dtype=input.dtype)
+                c_0 = torch.zeros(shape, device=input.device, dtype=input.dtype)
+            else:
+                h_0 = state[0][i].detach()
+                c_0 = state[1][i].detach()
+            h, c = layer(layer_input, (h_0, c_0))
+            h_fl.append(h[-1])
+            c_fl.append(c[-1])
+            all_h_fl.append(h)
+            all_c_fl.append(c)
+            x = h
+        return (x, (torch.stack(h_fl, dim=0), torch.stack(c_fl, dim=0)),
+                (torch.stack(all_h_fl, dim=0), torch.stack(all_c_fl, dim=0)))

@@ -1,0 +1,114 @@
+"""rnnt_ext.transducer.loss — RNN-T transducer loss module + autograd function.
+
+Interface mirror of training/lib/src/rnnt_ext/transducer/loss.py:43-253 (class names,
+argument order, defaults, assertions); the compute is the gfx950 C-ABI library
+(caiman_logsumexp, caiman_transducer_loss_forward / _backward).
+"""
+import math
+from typing import List, Optional
+
+import torch
+
+import caiman_asr_amd.rnnt_ext.cuda.logsumexp as logsumexp_cu
+import caiman_asr_amd.rnnt_ext.cuda.transducer_loss as transducer_loss_cu
+
+
+class TransducerLoss(torch.nn.Module):
+    """Transducer loss (Graves 2012) with delay / EOS / star penalties.
+
+    Arguments:
+        packed_input: whether the logits arrive packed ([sum_b T_b*(U_b+1), V], don't-care
+            cells removed) instead of padded [B, T, U+1, V].
+    """
+
+    def __init__(self, packed_input: bool = False):
+        super().__init__()
+        self.packed_input = packed_input
+        self.dummy_batch_offset = torch.empty(0)
+
+    def forward(
+        self,
+        x: torch.Tensor,
+        label: torch.Tensor,
+        f_len: torch.Tensor,
+        y_len: torch.Tensor,
+        blank_idx: int,
+        eos_idx: Optional[int] = None,
+        star_idx: Optional[int] = None,
+        batch_offset: Optional[torch.Tensor] = None,
+        max_f_len: Optional[int] = None,
+        debug_list: Optional[List[torch.Tensor]] = None,
+        delay_penalty: float = 0.0,
+        eos_penalty: float = 0.0,
+        star_penalty: float = 1.0,
+    ) -> torch.Tensor:
+        """Returns the per-utterance loss, shape (B,).  Argument meaning as in the reference
+        (training/lib/src/rnnt_ext/transducer/loss.py:78-113)."""
+        assert len(x.shape) == 4 or len(x.shape) == 2, "Shape (B, T, U, H) or (*, H)"
+        assert f_len.min() >= 1, "f_len must be non-negative"
+        assert y_len.min() >= 0, "y_len must be non-negative"
+        assert y_len.max() <= label.size(1), "y_len must be less than label length"
+
+        if self.packed_input:
+            if batch_offset is None or max_f_len is None:
+                raise Exception("Please specify batch_offset and max_f_len when packing is enabled")
+            my_batch_offset = batch_offset
+            my_max_f_len = max_f_len
+            assert my_max_f_len == f_len.max()
+        else:
+            my_batch_offset = self.dummy_batch_offset
+            my_max_f_len = x.size(1)
+
+        return TransducerLossFunc.apply(
+            x, label, f_len, y_len, my_batch_offset, delay_penalty, my_max_f_len, blank_idx,
+            eos_penalty, eos_idx, math.log(star_penalty), star_idx, debug_list, self.packed_input)
+
+
+class TransducerLossFunc(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx,
+                eos_penalty, eos_idx, star_penalty, star_idx, debug_list, packed_input):
+        if packed_input:
+            denom = logsumexp_cu.logsumexp(x, 128, True)
+        else:
+            assert x.is_contiguous(), "activations must be contiguous or packed"
+            denom = logsumexp_cu.logsumexp(x.view(-1, x.shape[-1]), 128, True).view(x.shape[:-1])
+        assert denom.shape == x.shape[:-1]
+
+        if eos_idx is None:
+            eos_idx = -1
+        else:
+            assert eos_idx != blank_idx, "eos_idx must be different from blank_idx"
+        if star_idx is None:
+            star_idx = -2
+        else:
+            assert star_idx != blank_idx, "star_idx must be different from blank_idx"
+        assert star_idx != eos_idx, "star_idx must be different from eos_idx"
+
+        alpha, beta, loss = transducer_loss_cu.forward(
+            x, denom, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx,
+            eos_penalty, eos_idx, star_penalty, star_idx, packed_input)
+
+        if debug_list == []:
+            debug_list += [alpha, beta]
+        ctx.save_for_backward(x, denom, alpha, beta, f_len, y_len, label, batch_offset)
+        ctx.blank_idx = blank_idx
+        ctx.eos_penalty = eos_penalty
+        ctx.eos_idx = eos_idx
+        ctx.star_penalty = star_penalty
+        ctx.star_idx = star_idx
+        ctx.packed_input = packed_input
+        ctx.max_f_len = max_f_len
+        ctx.delay_penalty = delay_penalty
+        return loss
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, loss_grad):
+        x, denom, alpha, beta, f_len, y_len, label, batch_offset = ctx.saved_tensors
+        x_grad = transducer_loss_cu.backward(
+            x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len, label, batch_offset,
+            ctx.delay_penalty, ctx.max_f_len, ctx.blank_idx, ctx.eos_penalty, ctx.eos_idx,
+            ctx.star_penalty, ctx.star_idx, ctx.packed_input)
+        return x_grad, *([None] * 13)

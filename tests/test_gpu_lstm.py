@@ -1,0 +1,167 @@
+"""GPU parity: HIP LSTM recurrent kernels (through the C-ABI) vs the CPU oracle and torch.nn.LSTM.
+
+Mirrors training/lib/tests/custom_lstm/test_cuda.py (value + gradient equality with torch.nn.LSTM,
+tolerances :193-200) and checks the op-level contract of lstm_fused_{fwd,bwd} (in-place activated
+gates, [T+1] state slabs) against oracle/rnnt_oracle.c.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _op_level(T, B, H, dtype, hard, seed=0):
+    from caiman_asr_amd.rnnt_ext.cuda import lstm as lstm_cu
+    from oracle import native
+
+    g = torch.Generator().manual_seed(seed)
+    R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dtype)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dtype)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dtype)
+    y0 = (torch.randn(B, H, generator=g) * 0.5).to(dtype)
+    delta = torch.randn(T, B, H, generator=g).to(dtype)
+
+    gd = gates.clone().to(DEV)
+    c = torch.zeros(T + 1, B, H, dtype=dtype, device=DEV)
+    y = torch.zeros(T + 1, B, H, dtype=dtype, device=DEV)
+    c[0] = c0.to(DEV)
+    y[0] = y0.to(DEV)
+    fwd = lstm_cu.lstm_fused_fwd_hard if hard else lstm_cu.lstm_fused_fwd_soft
+    bwd = lstm_cu.lstm_fused_bwd_hard if hard else lstm_cu.lstm_fused_bwd_soft
+    fwd(R.to(DEV), gd, c, y)
+    dG = torch.empty_like(gd)
+    bwd(R.to(DEV), gd, c, delta.to(DEV), dG)
+
+    og, oc, oy = native.lstm_fwd(R.double().numpy(), gates.double().numpy(), c0.double().numpy(),
+                                 y0.double().numpy(), hard=hard)
+    return (gd, c, y, dG), (og, oc, oy), (R, delta)
+
+
+@pytest.mark.parametrize("T,B,H", [(1, 1, 1), (7, 3, 5), (8, 4, 16), (5, 2, 70)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("hard", [False, True])
+def test_generic_kernels_match_oracle(T, B, H, dtype, hard):
+    from oracle import native
+
+    (gd, c, y, dG), (og, oc, oy), (R, delta) = _op_level(T, B, H, dtype, hard, seed=T * 7 + H)
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    assert np.allclose(gd.double().cpu().numpy(), og, atol=tol)
+    assert np.allclose(c.double().cpu().numpy(), oc, atol=tol)
+    assert np.allclose(y.double().cpu().numpy(), oy, atol=tol)
+    odG, _ = native.lstm_bwd(R.double().numpy(), gd.double().cpu().numpy(), c.double().cpu().numpy(),
+                             delta.double().numpy(), hard=hard)
+    assert np.allclose(dG.double().cpu().numpy(), odG, atol=tol * 10)
+
+
+@pytest.mark.parametrize("T,B,H", [(6, 32, 64), (9, 5, 128), (4, 40, 256), (3, 70, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hard", [False, True])
+def test_mfma_kernels_match_oracle(T, B, H, dtype, hard):
+    """Reduced-precision MFMA path. The oracle runs in f64 on the same rounded inputs; the only
+    differences are fp32 accumulation order and one rounding of each stored value, which then
+    feeds the next step — hence the bf16-resolution tolerance."""
+    from oracle import native
+
+    (gd, c, y, dG), (og, oc, oy), (R, delta) = _op_level(T, B, H, dtype, hard, seed=B + H)
+    tol = 4e-2 if dtype == torch.bfloat16 else 6e-3
+    assert np.allclose(gd.double().cpu().numpy(), og, atol=tol)
+    assert np.allclose(c.double().cpu().numpy(), oc, atol=tol * 2)
+    assert np.allclose(y.double().cpu().numpy(), oy, atol=tol)
+    # backward from the GPU's own (rounded) forward state so only the backward is compared
+    odG, _ = native.lstm_bwd(R.double().numpy(), gd.double().cpu().numpy(), c.double().cpu().numpy(),
+                             delta.double().numpy(), hard=hard)
+    got = dG.double().cpu().numpy()
+    if hard:
+        # clamp-boundary derivatives are decided on rounded activations: identical inputs, so equal
+        assert np.mean(np.abs(got - odG) > tol * 4) < 1e-3
+    else:
+        assert np.allclose(got, odG, atol=tol * 4, rtol=tol)
+
+
+def _pair(num_layers, I, H, dtype):
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    torch.manual_seed(3)
+    cand = CustomLSTM(I, H, num_layers, dtype=dtype, device=DEV)
+    ref = torch.nn.LSTM(I, H, num_layers, dtype=dtype, device=DEV)
+    with torch.no_grad():
+        for i in range(num_layers):
+            for pat in ("weight_ih_l{}", "weight_hh_l{}", "bias_ih_l{}", "bias_hh_l{}"):
+                getattr(ref, pat.format(i)).copy_(getattr(cand, pat.format(i)))
+    return cand, ref
+
+
+@pytest.mark.parametrize("seq_length", [1, 8])
+@pytest.mark.parametrize("num_layers", [1, 2, 4])
+@pytest.mark.parametrize("batch_size", [1, 4])
+@pytest.mark.parametrize("input_size", [1, 16])
+@pytest.mark.parametrize("hidden_size", [1, 16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_custom_lstm_matches_torch_lstm(seq_length, num_layers, batch_size, input_size, hidden_size, dtype):
+    # training/lib/tests/custom_lstm/test_cuda.py:174-217
+    cand, ref = _pair(num_layers, input_size, hidden_size, dtype)
+    tol = 1e-6 if dtype == torch.float32 else 1e-12
+    X1 = torch.randn(seq_length, batch_size, input_size, dtype=dtype, device=DEV, requires_grad=True)
+    X2 = X1.detach().clone().requires_grad_(True)
+    h0 = torch.randn(num_layers, batch_size, hidden_size, dtype=dtype, device=DEV)
+    c0 = torch.randn_like(h0)
+    o1, (h1, c1) = ref(X1, (h0, c0))
+    o2, (h2, c2), (all_h, all_c) = cand(X2, (h0, c0))
+    assert torch.allclose(o1, o2, atol=tol) and torch.allclose(h1, h2, atol=tol) and torch.allclose(c1, c2, atol=tol)
+    assert all_h.shape == (num_layers, seq_length, batch_size, hidden_size)
+    assert torch.equal(all_h[-1], o2) and torch.equal(all_c[:, -1], c2)
+    w = torch.randn_like(o1)
+    (o1 * w).sum().backward()
+    (o2 * w).sum().backward()
+    assert torch.allclose(X1.grad, X2.grad, atol=tol * 10)
+    for i in range(num_layers):
+        for pat in ("weight_ih_l{}", "weight_hh_l{}", "bias_ih_l{}", "bias_hh_l{}"):
+            a, b = getattr(ref, pat.format(i)).grad, getattr(cand, pat.format(i)).grad
+            assert torch.allclose(a, b, atol=tol * 10), pat.format(i)
+
+
+def test_custom_lstm_autocast_bf16_close_to_fp32():
+    cand, ref = _pair(2, 64, 128, torch.float32)
+    X = torch.randn(12, 6, 64, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        o2, _, _ = cand(X)
+    o1, _ = ref(X)
+    assert o2.dtype == torch.bfloat16
+    assert torch.allclose(o1, o2.float(), atol=3e-2)
+
+
+def test_state_passing_equivalence():
+    # model(concat(A,B)) == model(A) then model(B | state): training/tests/rnnt/test_model.py:107-296
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    torch.manual_seed(0)
+    m = CustomLSTM(8, 16, 2, dtype=torch.float64, device=DEV)
+    x = torch.randn(10, 3, 8, dtype=torch.float64, device=DEV)
+    full, (hf, cf), _ = m(x)
+    a, sa, _ = m(x[:4])
+    b, (hb, cb), _ = m(x[4:], sa)
+    assert torch.allclose(torch.cat([a, b]), full, atol=1e-12)
+    assert torch.allclose(hb, hf, atol=1e-12) and torch.allclose(cb, cf, atol=1e-12)
+
+
+def test_non_contiguous_delta_and_input_checks():
+    from caiman_asr_amd.rnnt_ext.cuda import lstm as lstm_cu
+
+    T, B, H = 4, 3, 8
+    R = torch.randn(4 * H, H, device=DEV)
+    gates = torch.randn(T, B, 4 * H, device=DEV)
+    c = torch.zeros(T + 1, B, H, device=DEV)
+    y = torch.zeros(T + 1, B, H, device=DEV)
+    lstm_cu.lstm_fused_fwd_soft(R, gates, c, y)
+    big = torch.randn(T, B, 2 * H, device=DEV)
+    d_nc = big[:, :, :H]  # row stride 2H
+    dG1, dG2 = torch.empty_like(gates), torch.empty_like(gates)
+    lstm_cu.lstm_fused_bwd_soft(R, gates, c, d_nc, dG1)
+    lstm_cu.lstm_fused_bwd_soft(R, gates, c, d_nc.contiguous(), dG2)
+    assert torch.equal(dG1, dG2)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        lstm_cu.lstm_fused_fwd_soft(R.t(), gates, c, y)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        lstm_cu.lstm_fused_fwd_soft(R.cpu(), gates, c, y)
