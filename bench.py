@@ -1,0 +1,243 @@
+"""bench.py — audio-hours/sec of base (85 M) RNN-T bf16 TRAINING on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic LibriSpeech-shaped input:
+  on-device SpecAugment + frame splicing -> encoder / prediction LSTMs -> packed joint ->
+  joint_fc -> transducer loss -> full backward -> (N>1: RCCL gradient all-reduce overlapped with
+  backward) -> LAMB + EMA update.
+Metric (BASELINE.json): audio-hours/sec = sum over ranks of sum(feat_lens) * 0.03 s / time / 3600,
+the reference's `throughput-audio-secs-per-sec` (training/caiman_asr_train/train.py:379-382) / 3600.
+
+  python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU).
+Rank 0 prints ONE JSON line with `roofline` (dominant hand-written kernel, HIP events) and, at
+N = 1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from argparse import Namespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FRAME_SECONDS = 0.03  # 10 ms hop x 3 frame subsampling (training/caiman_asr_train/utils/frame_width.py)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+BASE_RNNT = dict(  # training/configs/base-8703sp.yaml:73-94
+    in_feats=240, enc_n_hid=1024, enc_pre_rnn_layers=2, enc_post_rnn_layers=6, enc_stack_time_factor=2,
+    enc_dropout=0.1, enc_batch_norm=False, enc_freeze=False, pred_n_hid=512, pred_rnn_layers=2, pred_dropout=0.3,
+    pred_batch_norm=False, joint_n_hid=768, joint_dropout=0.3, joint_net_lr_factor=0.343,
+    joint_apex_transducer="pack", joint_apex_relu_dropout=True, forget_gate_bias=1.0, custom_lstm=True,
+    quantize=False, enc_rw_dropout=0.0, pred_rw_dropout=0.0)
+N_CLASSES = 8704  # 8703 sentencepieces + blank
+
+
+def make_batches(n_batches, batch_size, seed, n_mels=80):
+    """LibriSpeech-960-like utterances: duration ~ clip(N(12.3, 3.8), 1, 16.7) s,
+    ~3.3 tokens/s, sorted into 6 duration buckets like the reference's BucketingSampler; every batch
+    is drawn from one bucket.  Returns host tensors: log-mel [B, 80, T], frame lens, tokens, token lens."""
+    rng = np.random.default_rng(seed)
+    n_utts = n_batches * batch_size
+    dur = np.clip(rng.normal(12.3, 3.8, size=n_utts), 1.0, 16.7)
+    order = np.argsort(dur)
+    buckets = np.array_split(order, 6)
+    batches = []
+    per_bucket = [list(rng.permutation(b)) for b in buckets]
+    bi = 0
+    while len(batches) < n_batches:
+        pool = per_bucket[bi % 6]
+        bi += 1
+        if len(pool) < batch_size:
+            continue
+        idx = [pool.pop() for _ in range(batch_size)]
+        d = dur[idx]
+        frames = np.floor(d * 100).astype(np.int64)  # 10 ms hop
+        ntok = np.maximum(1, np.round(3.3 * d)).astype(np.int64)
+        T = int(frames.max())
+        g = torch.Generator().manual_seed(int(seed * 100003 + len(batches)))
+        feats = torch.randn(batch_size, n_mels, T, generator=g)
+        for i, f in enumerate(frames):
+            feats[i, :, f:] = 0
+        U = int(ntok.max())
+        txt = torch.randint(0, N_CLASSES - 1, (batch_size, U), generator=g)
+        batches.append((feats, torch.tensor(frames), txt, torch.tensor(ntok)))
+    return batches
+
+
+def cpu_baseline(model, threads):
+    """The CPU oracle (oracle/model.py + oracle/rnnt_oracle.c: a port, fp32 network / f64 loss) on
+    BASELINE config[0]: base-85M, 2 synthetic 1 s utterances, forward + RNN-T loss + backward."""
+    from oracle import model as omodel
+
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((34, 2, 240)).astype(np.float32)
+    x_lens = np.array([34, 34])
+    y = rng.integers(0, N_CLASSES - 1, size=(2, 5))
+    y_lens = np.array([5, 3])
+    cfg = dict(BASE_RNNT)
+    omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, N_CLASSES - 1, dtype=torch.float32)  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 3 or (time.perf_counter() - t0 < 10 and iters < 50):
+        omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, N_CLASSES - 1, dtype=torch.float32)
+        iters += 1
+    dt = (time.perf_counter() - t0) / iters
+    audio_s = float(x_lens.sum()) * FRAME_SECONDS
+    return {"value": audio_s / dt / 3600.0, "unit": "audio-hours/sec", "cores": threads, "kind": "port",
+            "sample": f"base-85M fp32, 2 utterances x 1.02 s (feats [34,2,240], U=[5,3]), fwd+loss+bwd, "
+                      f"{iters} iterations of {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.data.features import FrameSplicing, SpecAugment
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers, get_packing_meta_data
+    from caiman_asr_amd.rnnt.model import RNNT
+    from caiman_asr_amd.train_utils.distributed import FlatGradReducer, broadcast_parameters
+    from caiman_asr_amd.train_utils.lr import lr_policy
+    from caiman_asr_amd.train_utils.optimizer import build_optimizer
+
+    _lib.lib()  # fail loudly if the HIP library is missing
+
+    torch.manual_seed(1234)  # identical initial weights on every rank (then broadcast anyway)
+    model = RNNT(n_classes=N_CLASSES, **BASE_RNNT).to(dev)
+    model.train()
+    opt_args = Namespace(lr=4e-3, weight_decay=1e-2, beta1=0.9, beta2=0.999, clip_norm=1.0, ema=0.999)
+    optimizer = build_optimizer(opt_args, model)
+    initial_lrs = [g["lr"] for g in optimizer.param_groups]
+    broadcast_parameters(optimizer.flat_p)
+    reducer = FlatGradReducer(optimizer._params, optimizer._offsets, optimizer.flat_g) if world > 1 else None
+    loss_fn = ApexTransducerLoss(blank_idx=N_CLASSES - 1, eos_idx=None, star_idx=None, packed_input=True,
+                                 validate_first_n_remaining=0)
+    spec = SpecAugment(freq_masks=2, min_freq=0, max_freq=20, time_masks=10, min_time=0, max_time=0.03)
+    splice = FrameSplicing(frame_stacking=3, frame_subsampling=3)
+    loss_mods = LossModifiers(delay_penalty=0.0, eos_penalty=0.0, star_penalty=0.75)
+
+    n_distinct = min(args.steps + args.warmup, 12)
+    host_batches = make_batches(n_distinct, args.batch, seed=1 + rank)
+    # inputs resident in HBM before the timed region
+    dev_batches = [(f.to(dev), fl, t.to(dev), tl) for f, fl, t, tl in host_batches]
+
+    def step(i, global_step):
+        feats, feat_lens_h, txt, txt_lens_h = dev_batches[i % n_distinct]
+        lr_policy(optimizer, initial_lrs, 4e-4, global_step, 1632, 18000, 10880)
+        feat_lens_d = feat_lens_h.to(dev, non_blocking=True)
+        x, _ = spec((feats, feat_lens_d))
+        x, lens_h = splice((x, feat_lens_h))           # lens on the host: no device sync
+        x = x.permute(2, 0, 1).contiguous()            # PermuteAudio: [T1, B, 240]
+        meta = get_packing_meta_data(lens_h, txt_lens_h, 2, device=dev)
+        lens_d = lens_h.to(dev, non_blocking=True)
+        txt_lens_d = txt_lens_h.to(dev, non_blocking=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits, logit_lens, _ = model(x, lens_d, txt, txt_lens_d, batch_offset=meta["batch_offset"],
+                                          packed_batch=meta["packed_batch"])
+            loss = loss_fn(logits, logit_lens, txt, txt_lens_d, meta["batch_offset"], meta["max_f_len"], loss_mods)
+        del logits
+        loss.backward()   # a NaN loss gives NaN gradients -> the optimiser skips the update on-device
+        if reducer is not None:
+            reducer.finish()
+        optimizer.step(zero_grad=True)
+        return loss.detach(), float(lens_h.sum()) * FRAME_SECONDS, meta["packed_batch"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        last_loss, _, _ = step(i, i)
+        if i == 0:
+            loss_fn.t_loss.validate_lengths = False  # inputs validated once; no per-step host syncs
+    barrier()
+    if not args.no_kernel_timing:
+        _lib.timing.enabled = True
+        _lib.timing.reset()
+    audio_s, cells = 0.0, 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last_loss, a, c = step(args.warmup + i, args.warmup + i)
+        audio_s += a
+        cells += c
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.timing.enabled = False
+
+    stats = torch.tensor([elapsed, audio_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        asum = stats[1:2].clone()
+        dist.all_reduce(asum, op=dist.ReduceOp.SUM)
+        elapsed, audio_total = float(tmax.item()), float(asum.item())
+    else:
+        audio_total = audio_s
+
+    if rank == 0:
+        loss_val = float(last_loss.item())
+        out = {
+            "metric": "audio-hours/sec (base RNN-T training)", "value": audio_total / elapsed / 3600.0,
+            "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "base-85M RNN-T bf16 training, LibriSpeech-960 shapes, batch 32 per GPU "
+                                   "(BASELINE.json configs[1])",
+                       "global_batch": args.batch * world, "utterance_seconds": "clip(N(12.3,3.8),1,16.7)",
+                       "parallelism": f"dp{world}", "final_loss": loss_val,
+                       "audio_seconds_per_step": audio_total / args.steps},
+        }
+        if not args.no_kernel_timing:
+            summ = _lib.timing_summary()
+            out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in summ.items()}
+            # Roofline of the fused transducer-loss backward (HBM-bound): algorithmic bytes per cell
+            # = V*s read + V*s write ; one launch per step covers every packed cell.
+            if "loss_bwd" in summ:
+                n_launch, ms = summ["loss_bwd"]
+                alg_bytes = cells * N_CLASSES * 2 * 2
+                achieved = alg_bytes / (ms * 1e-3) / 1e9
+                out["roofline"] = {"kernel": "loss_bwd_kernel (transducer loss fused backward)", "bound": "hbm",
+                                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "avg_launch_ms": ms / n_launch, "launches": n_launch}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, threads=os.cpu_count() or 1)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

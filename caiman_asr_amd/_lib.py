@@ -73,6 +73,7 @@ I64 = ctypes.c_int64
 I32 = ctypes.c_int
 U32 = ctypes.c_uint32
 F64 = ctypes.c_double
+F32 = ctypes.c_float
 
 _SIGS = {
     "caiman_abi_version": ([], ctypes.c_int),
@@ -86,6 +87,11 @@ _SIGS = {
         [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
          P, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
+    "caiman_joint_forward": ([P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, F64, ctypes.c_uint64, I32, P, P],
+                             ctypes.c_int),
+    "caiman_joint_backward": ([P, P, P, P, P, I64, I64, I64, I64, I32, I32, F64, I32, P, P, P], ctypes.c_int),
+    "caiman_lamb_step": ([P, P, P, P, P, P, P, P, I64, P, P, I64, P, P, I32, F32, F32, F32, F32, F32, F32, I32, I32,
+                          I32, P, P, P], ctypes.c_int),
     "caiman_lstm_fused_bwd": ([P, P, P, P, I64, I64, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
 }
 
@@ -153,3 +159,45 @@ def check_input(t, name):
         raise RuntimeError(
             f"{name} must be contiguous but got shape{list(t.shape)} and strides {list(t.stride())} "
             f"such that numel is {t.numel()}")
+
+
+# ---- optional per-op HIP event timing (used by bench.py for the roofline line) -----------------
+class _Timing:
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self):
+        self.records = {}
+
+
+timing = _Timing()
+
+
+class timed:
+    """`with timed("name"):` brackets the enclosed launches with HIP events on the CURRENT stream
+    (the stream the kernels are launched on) when timing is enabled; otherwise it is free."""
+
+    __slots__ = ("name", "start")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if timing.enabled:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timing.enabled:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            timing.records.setdefault(self.name, []).append((self.start, end))
+        return False
+
+
+def timing_summary():
+    """{name: (calls, total_ms)}; synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in timing.records.items()}

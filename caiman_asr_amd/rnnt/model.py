@@ -1,0 +1,214 @@
+"""RNNT network: stacked-LSTM encoder with time stacking, LSTM prediction network, joint.
+
+Interface mirror of training/caiman_asr_train/rnnt/model.py (`StackTime` :35-49, `RNNT`
+:52-491, `label_collate` :494-519): same constructor keywords (so `RNNT(n_classes,
+**yaml['rnnt'])` works on the unchanged training/configs YAMLs), same method names, same
+parameter names / state_dict keys (checked against the reference's model_schema in tests).
+"""
+from itertools import chain
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from caiman_asr_amd.rnnt.joint import TransducerJoint
+from caiman_asr_amd.rnnt.rnn import rnn
+from caiman_asr_amd.rnnt.state import (EncoderState, PredNetState, RNNTState, get_pred_net_state,
+                                       maybe_get_last_nonpadded)
+
+
+class StackTime(nn.Module):
+    """out[t'] = cat(x[f*t'], ..., x[f*t'+f-1]) on the feature axis (zeros past the end);
+    lens' = ceil(lens / f).  One reshape instead of the reference's f shifted copies."""
+
+    def __init__(self, factor):
+        super().__init__()
+        self.factor = int(factor)
+
+    def forward(self, x, x_lens):
+        T, B, H = x.shape
+        f = self.factor
+        pad = (-T) % f
+        if pad:
+            x = torch.cat([x, x.new_zeros(pad, B, H)], 0)
+        x = x.view((T + pad) // f, f, B, H).transpose(1, 2).reshape((T + pad) // f, B, f * H)
+        return x, (x_lens.int() + f - 1) // f
+
+
+class RNNT(nn.Module):
+    """Recurrent Neural Network Transducer.  Argument meaning: reference model.py:55-77."""
+
+    def __init__(self, n_classes, in_feats, enc_n_hid, enc_batch_norm, pred_batch_norm, enc_pre_rnn_layers,
+                 enc_post_rnn_layers, enc_stack_time_factor, enc_dropout, pred_dropout, joint_dropout,
+                 pred_n_hid, pred_rnn_layers, joint_n_hid, forget_gate_bias, custom_lstm=False, quantize=False,
+                 enc_rw_dropout=0.0, pred_rw_dropout=0.0, hidden_hidden_bias_scale=0.0, weights_init_scale=1.0,
+                 enc_lr_factor=1.0, pred_lr_factor=1.0, joint_enc_lr_factor=1.0, joint_pred_lr_factor=1.0,
+                 joint_net_lr_factor=1.0, joint_apex_transducer=None, joint_apex_relu_dropout=False,
+                 enc_freeze=False, gpu_unavailable=False):
+        super().__init__()
+        if joint_apex_relu_dropout and not joint_apex_transducer:
+            raise ValueError("Can't have joint_apex_relu_dropout=True without bool(joint_apex_transducer)==True")
+        if joint_apex_transducer is not None:
+            assert joint_apex_transducer in {"pack", "not_pack"}
+        self._module_to_lr_factor = {
+            "encoder": enc_lr_factor, "prediction": pred_lr_factor, "joint_enc": joint_enc_lr_factor,
+            "joint_pred": joint_pred_lr_factor, "joint_net": joint_net_lr_factor}
+        self.pred_n_hid = pred_n_hid
+        self.enc_stack_time_factor = enc_stack_time_factor
+
+        common = dict(forget_gate_bias=forget_gate_bias, custom_lstm=custom_lstm, quantize=quantize,
+                      hidden_hidden_bias_scale=hidden_hidden_bias_scale, weights_init_scale=weights_init_scale,
+                      gpu_unavailable=gpu_unavailable)
+        self.encoder = nn.ModuleDict({
+            "pre_rnn": rnn(input_size=in_feats, hidden_size=enc_n_hid, num_layers=enc_pre_rnn_layers,
+                           batch_norm=enc_batch_norm, rw_dropout=enc_rw_dropout, dropout=enc_dropout,
+                           tensor_name="pre_rnn", **common),
+            "stack_time": StackTime(enc_stack_time_factor),
+            "post_rnn": rnn(input_size=enc_stack_time_factor * enc_n_hid, hidden_size=enc_n_hid,
+                            num_layers=enc_post_rnn_layers, batch_norm=enc_batch_norm, rw_dropout=enc_rw_dropout,
+                            dropout=enc_dropout, tensor_name="post_rnn", **common),
+        })
+        self.encoder.requires_grad_(not enc_freeze)
+        self.prediction = nn.ModuleDict({
+            "embed": nn.Embedding(n_classes - 1, pred_n_hid),  # blank is never an input
+            "dec_rnn": rnn(input_size=pred_n_hid, hidden_size=pred_n_hid, num_layers=pred_rnn_layers,
+                           batch_norm=pred_batch_norm, rw_dropout=pred_rw_dropout, dropout=pred_dropout,
+                           tensor_name="dec_rnn", **common),
+        })
+        self.joint_pred = nn.Linear(pred_n_hid, joint_n_hid)
+        self.joint_enc = nn.Linear(enc_n_hid, joint_n_hid)
+        self.joint_net = nn.Sequential(nn.ReLU(inplace=True), nn.Dropout(p=joint_dropout),
+                                       nn.Linear(joint_n_hid, n_classes))
+        self.relu_drop = self.joint_net[:2]
+        self.joint_fc = self.joint_net[-1]
+        self.joint_apex_transducer = joint_apex_transducer
+        if joint_apex_transducer is not None:
+            pack_output = joint_apex_transducer == "pack"
+            if joint_apex_relu_dropout:
+                self.apex_joint = TransducerJoint(pack_output=pack_output, relu=True, dropout=True,
+                                                  dropout_prob=joint_dropout)
+            else:
+                self.apex_joint = TransducerJoint(pack_output=pack_output)
+
+    # ---- forward pieces -------------------------------------------------------
+    def enc_pred(self, x, x_lens, y, y_lens, pred_net_state: Optional[PredNetState] = None,
+                 enc_state: Optional[EncoderState] = None):
+        return self.enc_pred_static(x, x_lens, y, y_lens, self.encode, self.predict,
+                                    pred_net_state=pred_net_state, enc_state=enc_state)
+
+    @staticmethod
+    def enc_pred_static(x, x_lens, y, y_lens, encode, predict, pred_net_state: Optional[PredNetState] = None,
+                        enc_state: Optional[EncoderState] = None):
+        y = label_collate(y)
+        f, x_lens, new_enc_state = encode(x, x_lens, enc_state=enc_state)
+        g, _, all_pred_hid = predict(
+            y, pred_state=(pred_net_state.next_to_last_pred_state if pred_net_state else None), add_sos=True,
+            special_sos=pred_net_state.last_token if pred_net_state else None)
+        g_lens = y_lens + 1
+        new_pred = get_pred_net_state(y, all_pred_hid, y_lens, g_lens)
+        rnnt_state = None
+        if new_enc_state is not None and new_pred is not None:
+            rnnt_state = RNNTState(enc_state=new_enc_state, pred_net_state=new_pred)
+        return (f, x_lens), (g, g_lens), rnnt_state
+
+    def forward(self, x, x_lens, y, y_lens, pred_net_state: Optional[PredNetState] = None, batch_offset=None,
+                enc_state: Optional[EncoderState] = None, packed_batch: Optional[int] = None):
+        """`packed_batch` (= batch_offset[-1], known on the host from get_packing_meta_data) is an
+        optional extra over the reference signature that avoids a device sync in `joint`."""
+        (f, x_lens), (g, g_lens), new_state = self.enc_pred(x, x_lens, y, y_lens, pred_net_state=pred_net_state,
+                                                            enc_state=enc_state)
+        out = self.joint(f, g, x_lens, g_lens, batch_offset, packed_batch=packed_batch)
+        return out, x_lens, new_state
+
+    def encode(self, x, x_lens, enc_state: Optional[EncoderState] = None):
+        """x [T,B,I], x_lens [B] -> f [B,T',Hj], lens', EncoderState|None."""
+        x, _, all_pre = self.encoder["pre_rnn"](x, enc_state.pre_rnn if enc_state else None)
+        pre_last = maybe_get_last_nonpadded(all_pre, x_lens)
+        x, x_lens = self.encoder["stack_time"](x, x_lens)
+        x, _, all_post = self.encoder["post_rnn"](x, enc_state.post_rnn if enc_state else None)
+        post_last = maybe_get_last_nonpadded(all_post, x_lens)
+        x = self.joint_enc(x.transpose(0, 1))
+        new_state = None
+        if all_pre is not None and all_post is not None:
+            new_state = EncoderState(pre_rnn=pre_last, post_rnn=post_last)
+        return x, x_lens, new_state
+
+    def predict(self, y, pred_state=None, add_sos: bool = True, special_sos=None):
+        """y [B,U] (or None for a single zero-embedding step) -> g [B,U+1,Hj], (h,c), all states."""
+        if y is not None:
+            y = self.prediction["embed"](y)
+        else:
+            B = 1 if pred_state is None else pred_state[0].size(1)
+            y = torch.zeros((B, 1, self.pred_n_hid), device=self.joint_enc.weight.device,
+                            dtype=self.joint_enc.weight.dtype)
+        if add_sos:
+            B, U, H = y.shape
+            if special_sos is None:
+                start = torch.zeros((B, 1, H), device=y.device, dtype=y.dtype)
+            else:
+                start = self.prediction["embed"](special_sos).to(device=y.device, dtype=y.dtype)
+            y = torch.cat([start, y], dim=1).contiguous()
+        y = y.transpose(0, 1)
+        g, hid, all_hid = self.prediction["dec_rnn"](y, pred_state)
+        g = self.joint_pred(g.transpose(0, 1))
+        return g, hid, all_hid
+
+    def joint(self, f, g, f_len=None, g_len=None, batch_offset=None, packed_batch: Optional[int] = None):
+        """f [B,T,H], g [B,U+1,H] -> logits [B,T,U+1,V], or packed [rows,V] when the joint packs."""
+        if self.joint_apex_transducer is None or f_len is None or g_len is None:
+            h = self.relu_drop(self.torch_transducer_joint(f, g, f_len, g_len))
+        else:
+            assert batch_offset is not None
+            if packed_batch is None:
+                packed_batch = batch_offset[-1].item()
+            h = self.apex_joint(f, g, f_len, g_len, batch_offset=batch_offset, packed_batch=packed_batch)
+            if not self.apex_joint.relu:
+                h = self.relu_drop(h)
+        return self.joint_fc(h)
+
+    @staticmethod
+    def torch_transducer_joint(f, g, f_len=None, g_len=None):
+        return f.unsqueeze(2) + g.unsqueeze(1)
+
+    # ---- optimiser / checkpoint surface ------------------------------------------
+    def param_groups(self, lr, return_module_name=False):
+        out = []
+        for name, lr_factor in self._module_to_lr_factor.items():
+            res = {"params": self._chain_params(getattr(self, name)), "lr": lr * lr_factor}
+            if return_module_name:
+                res["module_name"] = name
+            out.append(res)
+        return out
+
+    def _chain_params(self, *layers):
+        return chain(*[layer.parameters() for layer in layers])
+
+    def state_dict(self, *args, **kwargs):
+        """joint_fc.* are aliases of joint_net.2.* and are dropped (model.py:464-473)."""
+        sd = super().state_dict(*args, **kwargs)
+        prefix = kwargs.get("prefix", "")
+        sd.pop(prefix + "joint_fc.weight", None)
+        sd.pop(prefix + "joint_fc.bias", None)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        state_dict = dict(state_dict)
+        if "joint_net.2.weight" in state_dict:
+            state_dict["joint_fc.weight"] = state_dict["joint_net.2.weight"].detach().clone()
+        if "joint_net.2.bias" in state_dict:
+            state_dict["joint_fc.bias"] = state_dict["joint_net.2.bias"].detach().clone()
+        return super().load_state_dict(state_dict, strict=strict)
+
+
+def label_collate(labels):
+    """List of label index lists -> padded LongTensor [B, Umax]; tensors pass through as int64."""
+    if isinstance(labels, torch.Tensor):
+        return labels.type(torch.int64)
+    if not isinstance(labels, (list, tuple)):
+        raise ValueError(f"`labels` should be a list or tensor not {type(labels)}")
+    max_len = max(len(label) for label in labels)
+    cat = np.zeros((len(labels), max_len), dtype=np.int32)
+    for e, lab in enumerate(labels):
+        cat[e, :len(lab)] = lab
+    return torch.LongTensor(cat)

@@ -22,7 +22,8 @@ def logsumexp(input: torch.Tensor, max_threads: int = 128, promote: bool = False
     out_dtype = _lib.acc_dtype(input.dtype) if promote else input.dtype
     out = torch.empty((rows,), dtype=out_dtype, device=input.device)
     stride = input.stride(0) if rows > 1 else max(n, 1)
-    _lib.check(_lib.lib().caiman_logsumexp(
-        _lib.ptr(input), rows, n, stride, _lib.dtype_tag(input.dtype), _lib.ptr(out),
-        _lib.dtype_tag(out_dtype), int(max_threads), _lib.stream()))
+    with _lib.timed("logsumexp"):
+        _lib.check(_lib.lib().caiman_logsumexp(
+            _lib.ptr(input), rows, n, stride, _lib.dtype_tag(input.dtype), _lib.ptr(out),
+            _lib.dtype_tag(out_dtype), int(max_threads), _lib.stream()))
     return out

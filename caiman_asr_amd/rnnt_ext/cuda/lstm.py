@@ -22,9 +22,10 @@ def _fwd(R, gates, c, y, hard):
     if R.shape != (4 * H, H) or gates.numel() != T * B * 4 * H or c.size(0) != T + 1 or y.shape != c.shape:
         raise RuntimeError(f"inconsistent LSTM shapes R{list(R.shape)} gates{list(gates.shape)} "
                            f"c{list(c.shape)} y{list(y.shape)}")
-    _lib.check(_lib.lib().caiman_lstm_fused_fwd(
-        _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(y), T, B, H, _lib.dtype_tag(gates.dtype),
-        int(hard), _lib.stream()))
+    with _lib.timed("lstm_fwd"):
+        _lib.check(_lib.lib().caiman_lstm_fused_fwd(
+            _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(y), T, B, H, _lib.dtype_tag(gates.dtype),
+            int(hard), _lib.stream()))
 
 
 def _bwd(R, gates, c, delta, dG, hard):
@@ -42,10 +43,11 @@ def _bwd(R, gates, c, delta, dG, hard):
     dC = torch.empty((B, H), dtype=_lib.acc_dtype(gates.dtype), device=gates.device)
     use_rt = gates.dtype in (torch.float16, torch.bfloat16) and H % 64 == 0
     Rt = torch.empty((H, 4 * H), dtype=R.dtype, device=R.device) if use_rt else None
-    _lib.check(_lib.lib().caiman_lstm_fused_bwd(
-        _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(d), d.stride(0), d.stride(1), _lib.ptr(dG),
-        _lib.ptr(dC), _lib.ptr(Rt) if Rt is not None else None, T, B, H, _lib.dtype_tag(gates.dtype),
-        int(hard), _lib.stream()))
+    with _lib.timed("lstm_bwd"):
+        _lib.check(_lib.lib().caiman_lstm_fused_bwd(
+            _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(d), d.stride(0), d.stride(1), _lib.ptr(dG),
+            _lib.ptr(dC), _lib.ptr(Rt) if Rt is not None else None, T, B, H, _lib.dtype_tag(gates.dtype),
+            int(hard), _lib.stream()))
 
 
 def lstm_fused_fwd_soft(R, gates, c, y):

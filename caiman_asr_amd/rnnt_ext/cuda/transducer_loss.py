@@ -26,11 +26,12 @@ def forward(x, denom, label, aud_len, txt_len, batch_offset, dp_lam, max_flen, b
     alpha = torch.empty((batch, max_flen, max_glen), dtype=acc, device=x.device)
     beta = torch.empty((batch, max_flen, max_glen), dtype=acc, device=x.device)
     loss = torch.empty((batch,), dtype=acc, device=x.device)
-    _lib.check(_lib.lib().caiman_transducer_loss_forward(
-        _lib.ptr(x), _lib.ptr(denom), _lib.ptr(label), _lib.ptr(aud_len), _lib.ptr(txt_len),
-        _lib.ptr(batch_offset) if packed else None, batch, int(max_flen), max_glen, V, float(dp_lam),
-        int(blank_idx), float(eos_lam), int(eos_idx), float(star_lam), int(star_idx), int(bool(packed)),
-        _lib.dtype_tag(x.dtype), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(loss), _lib.stream()))
+    with _lib.timed("loss_fwd"):
+        _lib.check(_lib.lib().caiman_transducer_loss_forward(
+            _lib.ptr(x), _lib.ptr(denom), _lib.ptr(label), _lib.ptr(aud_len), _lib.ptr(txt_len),
+            _lib.ptr(batch_offset) if packed else None, batch, int(max_flen), max_glen, V, float(dp_lam),
+            int(blank_idx), float(eos_lam), int(eos_idx), float(star_lam), int(star_idx), int(bool(packed)),
+            _lib.dtype_tag(x.dtype), _lib.ptr(alpha), _lib.ptr(beta), _lib.ptr(loss), _lib.stream()))
     return [alpha, beta, loss]
 
 
@@ -50,10 +51,11 @@ def backward(x, denom, loss_grad, alpha, beta, aud_len, txt_len, label, batch_of
         loss_grad = loss_grad.to(acc)
     x_grad = torch.empty_like(x)
     total_rows = x.numel() // V if V > 0 else 0
-    _lib.check(_lib.lib().caiman_transducer_loss_backward(
-        _lib.ptr(x), _lib.ptr(denom), _lib.ptr(loss_grad), _lib.ptr(alpha), _lib.ptr(beta),
-        _lib.ptr(aud_len), _lib.ptr(txt_len), _lib.ptr(label),
-        _lib.ptr(batch_offset) if packed else None, batch, int(max_flen), max_glen, V, total_rows,
-        float(dp_lam), int(blank_idx), float(eos_lam), int(eos_idx), float(star_lam), int(star_idx),
-        int(bool(packed)), _lib.dtype_tag(x.dtype), _lib.ptr(x_grad), _lib.stream()))
+    with _lib.timed("loss_bwd"):
+        _lib.check(_lib.lib().caiman_transducer_loss_backward(
+            _lib.ptr(x), _lib.ptr(denom), _lib.ptr(loss_grad), _lib.ptr(alpha), _lib.ptr(beta),
+            _lib.ptr(aud_len), _lib.ptr(txt_len), _lib.ptr(label),
+            _lib.ptr(batch_offset) if packed else None, batch, int(max_flen), max_glen, V, total_rows,
+            float(dp_lam), int(blank_idx), float(eos_lam), int(eos_idx), float(star_lam), int(star_idx),
+            int(bool(packed)), _lib.dtype_tag(x.dtype), _lib.ptr(x_grad), _lib.stream()))
     return x_grad

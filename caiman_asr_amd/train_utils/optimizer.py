@@ -1,0 +1,132 @@
+"""FusedLAMB on a flat fp32 arena (+ fused EMA and gradient zeroing) backed by csrc/optimizer.hip.
+
+Constructor keywords follow apex.optimizers.FusedLAMB as the reference calls it
+(training/caiman_asr_train/train_utils/build_optimizer.py:11-32).  On construction every
+parameter is re-homed into ONE contiguous fp32 buffer (param.data and param.grad become views),
+so the optimiser is three streaming passes over HBM and data-parallel training can all-reduce
+contiguous slices of the gradient arena without bucket copies.
+"""
+from argparse import Namespace
+from typing import Optional
+
+import torch
+
+from caiman_asr_amd import _lib
+
+_ALIGN = 64          # elements; keeps every tensor 256-byte aligned in the arena
+_CHUNK = 1 << 16     # elements per workgroup chunk
+
+
+class FusedLAMB(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                 amsgrad=False, adam_w_mode=True, grad_averaging=True, set_grad_none=True, max_grad_norm=1.0,
+                 use_nvlamb=False, ema_decay: Optional[float] = None):
+        if amsgrad:
+            raise RuntimeError("FusedLAMB does not support the AMSGrad variant.")
+        if not adam_w_mode or use_nvlamb:
+            raise RuntimeError("only adam_w_mode=True, use_nvlamb=False (the reference's setting) is implemented")
+        defaults = dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps, weight_decay=weight_decay,
+                        grad_averaging=grad_averaging, max_grad_norm=max_grad_norm)
+        super().__init__(params, defaults)
+        if len(self.param_groups) > 16:
+            raise RuntimeError("at most 16 parameter groups")
+        self.ema_decay = ema_decay
+        self.set_grad_none = False  # grads are persistent views into the arena
+        self._build_arena()
+
+    # ---- arena ----------------------------------------------------------------------
+    def _build_arena(self):
+        plist, pgroup = [], []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if not p.requires_grad:
+                    continue
+                if p.dtype != torch.float32:
+                    raise RuntimeError("FusedLAMB arena expects fp32 master parameters")
+                if not p.is_cuda:
+                    raise RuntimeError("FusedLAMB: parameters must be CUDA tensors (no CPU optimiser path)")
+                plist.append(p)
+                pgroup.append(gi)
+        if not plist:
+            raise RuntimeError("FusedLAMB: no trainable parameters")
+        dev = plist[0].device
+        offsets, total = [], 0
+        for p in plist:
+            offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        chunk_start, chunk_len, chunk_tensor, first_chunk = [], [], [], []
+        for ti, (p, off) in enumerate(zip(plist, offsets)):
+            n = p.numel()
+            view = self.flat_p[off:off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + n].view(p.shape)
+            first_chunk.append(len(chunk_start))
+            for s in range(0, n, _CHUNK):
+                chunk_start.append(off + s)
+                chunk_len.append(min(_CHUNK, n - s))
+                chunk_tensor.append(ti)
+        first_chunk.append(len(chunk_start))
+        self.flat_ema = self.flat_p.clone() if self.ema_decay is not None else None
+        self._params, self._offsets = plist, offsets
+        self._n_chunks, self._n_tensors = len(chunk_start), len(plist)
+        self._chunk_start = torch.tensor(chunk_start, dtype=torch.int64, device=dev)
+        self._chunk_len = torch.tensor(chunk_len, dtype=torch.int32, device=dev)
+        self._chunk_tensor = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
+        self._first_chunk = torch.tensor(first_chunk, dtype=torch.int64, device=dev)
+        self._tensor_group = torch.tensor(pgroup, dtype=torch.int32, device=dev)
+        self._work = torch.zeros(8 + 2 * self._n_chunks + self._n_tensors, dtype=torch.float32, device=dev)
+        self._step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    @property
+    def grad_norm(self) -> torch.Tensor:
+        """Global gradient L2 norm of the last step() (device scalar, no sync)."""
+        return self._work[0]
+
+    @property
+    def last_step_applied(self) -> torch.Tensor:
+        return self._work[2]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+
+    def ema_tensors(self):
+        """{parameter -> EMA view}; the EMA model is what the reference evaluates / exports."""
+        assert self.flat_ema is not None
+        return {p: self.flat_ema[o:o + p.numel()].view(p.shape) for p, o in zip(self._params, self._offsets)}
+
+    @torch.no_grad()
+    def step(self, closure=None, inv_grad_scale: float = 1.0, zero_grad: bool = False):
+        import ctypes
+
+        g0 = self.param_groups[0]
+        n_groups = len(self.param_groups)
+        lrs = (ctypes.c_float * n_groups)(*[float(g["lr"]) for g in self.param_groups])
+        wds = (ctypes.c_float * n_groups)(*[float(g["weight_decay"]) for g in self.param_groups])
+        with _lib.timed("lamb"):
+            _lib.check(_lib.lib().caiman_lamb_step(
+                _lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v),
+                _lib.ptr(self.flat_ema) if self.flat_ema is not None else None, _lib.ptr(self._chunk_start),
+                _lib.ptr(self._chunk_len), _lib.ptr(self._chunk_tensor), self._n_chunks, _lib.ptr(self._tensor_group),
+                _lib.ptr(self._first_chunk), self._n_tensors, ctypes.cast(lrs, ctypes.c_void_p),
+                ctypes.cast(wds, ctypes.c_void_p), n_groups, float(g0["betas"][0]), float(g0["betas"][1]),
+                float(g0["eps"]), float(g0["max_grad_norm"] or 0.0),
+                float(self.ema_decay if self.ema_decay is not None else 0.0), float(inv_grad_scale),
+                int(bool(g0["bias_correction"])), int(bool(g0["grad_averaging"])), int(zero_grad),
+                _lib.ptr(self._work), _lib.ptr(self._step), _lib.stream()))
+        return None
+
+
+def build_fused_lamb(args: Namespace, model, opt_eps: float) -> FusedLAMB:
+    kw = {"params": model.param_groups(args.lr), "lr": args.lr, "weight_decay": args.weight_decay}
+    return FusedLAMB(betas=(args.beta1, args.beta2), eps=opt_eps, max_grad_norm=args.clip_norm,
+                     ema_decay=getattr(args, "ema", None) or None, **kw)
+
+
+def build_optimizer(args: Namespace, model) -> FusedLAMB:
+    """Top-level optimizer builder (eps = 1e-9, build_optimizer.py:27-32)."""
+    return build_fused_lamb(args, model, 1e-9)

@@ -123,6 +123,57 @@ int caiman_lstm_fused_bwd(const void* R, const void* gates, const void* c, const
                           void* Rt, int64_t T, int64_t B, int64_t H, int dtype, int hard,
                           caiman_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
+ * vendored; call sites training/caiman_asr_train/rnnt/model.py:228-238,425-434; CPU
+ * equivalent `torch_transducer_joint` + `relu_drop`, model.py:441-447,224).
+ * f : [B, T, H]   g : [B, U, H] (U = max label length + 1)   f_len, g_len : [B] int32
+ * out : packed [total_rows, H] (row = batch_offset[b-1] + t*g_len[b] + u) or padded
+ *       [B, T, U, H] with -1 in the don't-care cells (training/tests/rnnt/test_model.py:34-64)
+ * relu / dropout_p : fused ReLU and inverted dropout (p = 0 disables; `seed` drives this
+ *       library's counter-based mask generator).
+ * ------------------------------------------------------------------------- */
+int caiman_joint_forward(const void* f, const void* g, const int32_t* f_len,
+                         const int32_t* g_len, const int64_t* batch_offset, int64_t B,
+                         int64_t T, int64_t U, int64_t H, int64_t total_rows, int packed,
+                         int relu, double dropout_p, uint64_t seed, int dtype, void* out,
+                         caiman_stream_t stream);
+
+/* dh : gradient w.r.t. `out` (same layout); h_out : the forward output (mask source).
+ * mask_mode 0: none, 1: relu(+dropout) -> (h_out > 0), 2: dropout only -> (h_out != 0);
+ * scale = 1/(1-p).  df : [B, T, H], dg : [B, U, H] (rows beyond f_len / g_len zeroed). */
+int caiman_joint_backward(const void* dh, const void* h_out, const int32_t* f_len,
+                          const int32_t* g_len, const int64_t* batch_offset, int64_t B,
+                          int64_t T, int64_t U, int64_t H, int packed, int mask_mode,
+                          double scale, int dtype, void* df, void* dg,
+                          caiman_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * LAMB + EMA step over a flat fp32 arena — replaces apex.optimizers.FusedLAMB (third party;
+ * call site training/caiman_asr_train/train_utils/build_optimizer.py:11-32), the finite-
+ * gradient skip of training/caiman_asr_train/train_utils/optimizer.py:31-57 and the EMA loop
+ * of training/caiman_asr_train/train.py:58-64.
+ * p, g, m, v, ema : device arenas of equal length (ema may be NULL); tensors are laid out
+ *   back to back at 16-byte aligned offsets and cut into chunks (<= 2^31 elements each):
+ *   chunk_start[c] (element offset), chunk_len[c], chunk_tensor[c]; tensor_first_chunk[t]
+ *   (n_tensors + 1 entries), tensor_group[t].  These tables live on the DEVICE.
+ * group_lr / group_wd : HOST arrays, n_groups <= 16 entries (passed by value to the kernels).
+ * inv_grad_scale : 1/loss_scale (1 for bf16).  Non-finite gradient norm => p, m, v and the
+ *   device step counter are left untouched (EMA still advances, as in the reference).
+ * zero_grad : also clear g in the last pass (g otherwise holds the LAMB update on return).
+ * work : device scratch of 8 + 2*n_chunks + n_tensors floats; work[0] = gradient norm,
+ *        work[2] = 1 if the step was applied.
+ * ------------------------------------------------------------------------- */
+int caiman_lamb_step(float* p, float* g, float* m, float* v, float* ema,
+                     const int64_t* chunk_start, const int32_t* chunk_len,
+                     const int32_t* chunk_tensor, int64_t n_chunks,
+                     const int32_t* tensor_group, const int64_t* tensor_first_chunk,
+                     int64_t n_tensors, const float* group_lr, const float* group_wd,
+                     int n_groups, float beta1, float beta2, float eps, float max_grad_norm,
+                     float ema_decay, float inv_grad_scale, int bias_correction,
+                     int grad_averaging, int zero_grad, float* work, int32_t* step_counter,
+                     caiman_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,188 @@
+"""Generate golden vectors from the REFERENCE's own Python (CPU) -> tests/golden/*.npz|json.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the authoring container only (it imports
+/root/reference, which does not exist on the GPU box); the outputs are small data files
+(inputs + expected outputs + random-init weights), never source text.
+
+The reference imports packages this image lacks (beartype, jaxtyping, apex, kenlm, cerberus).
+They are type-annotation / third-party-op shims irrelevant to the CPU arithmetic exercised here,
+so they are replaced by in-memory no-op stand-ins (nothing is written anywhere):
+  beartype.beartype / jaxtyping.jaxtyped -> identity decorators,
+  apex TransducerJoint -> unused placeholder (joint_apex_transducer=None selects the reference's
+  own `torch_transducer_joint`),
+  rnnt_ext.cuda.{logsumexp,transducer_loss} (CUDA-only binaries) -> empty modules, never called.
+
+Usage:  python oracle/gen_golden.py
+"""
+import json
+import os
+import sys
+import types
+import typing
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/training"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def ident(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    stub("beartype", beartype=ident)
+    btt = stub("beartype.typing")
+    btt.__dict__.update({k: getattr(typing, k) for k in dir(typing) if not k.startswith("_")})
+
+    class _Sub:
+        def __class_getitem__(cls, item):
+            return typing.Any
+
+    stub("jaxtyping", jaxtyped=lambda **k: (lambda f: f), Int=_Sub, Float=_Sub, Bool=_Sub, Shaped=_Sub)
+    stub("apex")
+    stub("apex.contrib")
+
+    class TransducerJoint:  # never called: joint_apex_transducer=None below
+        def __init__(self, *a, **k):
+            pass
+
+    stub("apex.contrib.transducer", TransducerJoint=TransducerJoint)
+    stub("kenlm")
+    stub("cerberus")
+    # the compiled CUDA extensions cannot exist here; only pure-Python helpers of the modules
+    # that import them (get_packing_meta_data) are used below.
+    sys.path.insert(0, os.path.join(REF, "lib", "src"))
+    import rnnt_ext.cuda  # noqa: F401  (the reference's empty package)
+
+    stub("rnnt_ext.cuda.logsumexp")
+    stub("rnnt_ext.cuda.transducer_loss")
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "lib", "src"))
+
+
+def main():
+    _install_stubs()
+    import numpy as np
+    import torch
+    import yaml
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+
+    from caiman_asr_train.data.features import stack_subsample_frames
+    from caiman_asr_train.rnnt.batched_greedy import RNNTBatchedGreedyDecoder
+    from caiman_asr_train.rnnt.loss import get_packing_meta_data
+    from caiman_asr_train.rnnt.model import RNNT, StackTime
+    from caiman_asr_train.train_utils.lr import lr_policy
+
+    # ---- 1. state_dict schema of the shipped configs (shapes only) -----------------
+    for name in ("base", "large"):
+        schema = json.load(open(f"{REF}/caiman_asr_train/export/model_schema/{name}.json"))
+        json.dump(schema, open(os.path.join(OUT, f"schema_{name}.json"), "w"), indent=0)
+    for name, n_classes in (("base-8703sp", 8704), ("large-17407sp", 17408)):
+        cfg = yaml.safe_load(open(f"{REF}/configs/{name}.yaml"))["rnnt"]
+        json.dump(cfg, open(os.path.join(OUT, f"rnnt_cfg_{name.split('-')[0]}.json"), "w"), indent=0)
+
+    # ---- 2. mini models: weights + forward outputs --------------------------------------
+    def mini_cfg(enc, pred, joint, in_feats):
+        return dict(in_feats=in_feats, enc_n_hid=enc, enc_batch_norm=False, pred_batch_norm=False,
+                    enc_pre_rnn_layers=2, enc_post_rnn_layers=3, enc_stack_time_factor=2, enc_dropout=0.0,
+                    pred_dropout=0.0, joint_dropout=0.0, pred_n_hid=pred, pred_rnn_layers=2, joint_n_hid=joint,
+                    forget_gate_bias=1.0, custom_lstm=False, weights_init_scale=0.5,
+                    hidden_hidden_bias_scale=0.0, joint_net_lr_factor=0.343)
+
+    class _Tok:  # detokeniser stand-in: the decoder only calls sentpiece.id_to_piece
+        class sentpiece:
+            @staticmethod
+            def id_to_piece(i):
+                return f"<{i}>"
+
+    for tag, (enc, pred, joint, in_feats, V) in {"tiny": (11, 12, 13, 6, 30), "mfma": (64, 64, 32, 24, 30)}.items():
+        torch.manual_seed(1234)
+        cfg = mini_cfg(enc, pred, joint, in_feats)
+        m = RNNT(n_classes=V, **cfg).eval()
+        # random-init weights give a degenerate greedy path (one token repeated); widen them so
+        # blank / non-blank decisions and token identities vary across frames and utterances.
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.normal_(0.0, 0.35)
+            m.joint_net[2].bias[V - 1] += (0.6 if tag == "tiny" else 2.0)
+        T, B, U = 23, 3, 7
+        x = torch.randn(T, B, in_feats)
+        x_lens = torch.tensor([23, 17, 9])
+        y = torch.randint(0, V - 1, (B, U))
+        y_lens = torch.tensor([7, 4, 2])
+        with torch.no_grad():
+            f, f_lens, _ = m.encode(x, x_lens)
+            g, _, _ = m.predict(y)
+            logits, out_lens, _ = m(x, x_lens, y, y_lens)
+        # state passing: second half given the state of the first half (custom LSTM path is
+        # what produces states; with torch.nn.LSTM we emulate through encode on slices)
+        sd = {k: v.numpy() for k, v in m.state_dict().items()}
+        meta = get_packing_meta_data(x_lens, y_lens, 2)
+        # greedy decode through the reference decoder (token ids / frame indices are exact)
+        dec = RNNTBatchedGreedyDecoder(model=m, blank_idx=V - 1, eos_strategy=None, max_inputs_per_batch=int(1e7),
+                                       tokenizer=_Tok(), max_symbols_per_step=3)
+        res = dec.decode(x, x_lens)
+        toks, frames, confs = [], [], []
+        for per_utt in res:
+            tk, fr, cf = [], [], []
+            for t in sorted(per_utt):
+                hyp = per_utt[t].final.alternatives[0]
+                tk += hyp.y_seq
+                fr += hyp.timesteps
+                cf += hyp.confidence
+            toks.append(tk)
+            frames.append(fr)
+            confs.append(cf)
+        np.savez_compressed(
+            os.path.join(OUT, f"rnnt_{tag}.npz"), x=x.numpy(), x_lens=x_lens.numpy(), y=y.numpy(),
+            y_lens=y_lens.numpy(), f=f.numpy(), f_lens=f_lens.numpy(), g=g.numpy(), logits=logits.numpy(),
+            batch_offset=meta["batch_offset"].numpy(), max_f_len=np.array(meta["max_f_len"]),
+            cfg=json.dumps(cfg), n_classes=np.array(V),
+            greedy=json.dumps(dict(tokens=toks, frames=frames, confidence=confs)),
+            **{"sd." + k: v for k, v in sd.items()})
+        print(tag, "logits", tuple(logits.shape), "greedy", toks)
+
+    # ---- 3. small pure functions ---------------------------------------------------------
+    torch.manual_seed(7)
+    x = torch.randn(9, 2, 5)
+    lens = torch.tensor([9, 6])
+    st = {}
+    for fac in (2, 3):
+        o, l = StackTime(fac)(x, lens)
+        st[f"stack{fac}"] = o.numpy()
+        st[f"stack{fac}_lens"] = l.numpy()
+    a = torch.randn(2, 4, 10)
+    alens = torch.tensor([10, 7])
+    for (s, ss) in ((3, 3), (1, 1), (2, 1), (3, 2)):
+        o, l = stack_subsample_frames(a, alens, s, ss)
+        st[f"splice_{s}_{ss}"] = o.numpy()
+        st[f"splice_{s}_{ss}_lens"] = l.numpy()
+    np.savez_compressed(os.path.join(OUT, "shape_ops.npz"), x=x.numpy(), lens=lens.numpy(), a=a.numpy(),
+                        alens=alens.numpy(), **st)
+
+    class _Opt:
+        def __init__(self, n):
+            self.param_groups = [dict(lr=0.0) for _ in range(n)]
+
+    rows = []
+    init = [4e-3, 4e-3 * 0.343]
+    for step in (0, 1, 100, 1631, 1632, 5000, 19631, 19632, 25000, 60000, 200000):
+        o = _Opt(2)
+        lr_policy(o, init, 4e-4, step, 1632, 18000, 10880)
+        rows.append([step] + [g["lr"] for g in o.param_groups])
+    json.dump(dict(initial_lr=init, min_lr=4e-4, warmup=1632, hold=18000, half_life=10880, rows=rows),
+              open(os.path.join(OUT, "lr_policy.json"), "w"))
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

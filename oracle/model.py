@@ -1,0 +1,150 @@
+"""torch-CPU restatement of the RNN-T network + loss (float64 by default).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Follows
+training/caiman_asr_train/rnnt/model.py:297-447 (forward wiring), rnn.py:165-208 (LSTM stack),
+model.py:35-49 (StackTime), loss.py:112-125 (batch mean) and uses oracle/rnnt_oracle.c for the
+transducer loss.  Pinned by tests/golden/rnnt_*.npz, which were produced by the reference's own
+RNNT class (oracle/gen_golden.py).
+"""
+import math
+
+import numpy as np
+import torch
+
+from oracle import native
+
+
+def _lstm_stack(sd, prefix, x, num_layers, state=None):
+    """Plain-python multi-layer LSTM (gate order i,f,g,o)."""
+    T, B, _ = x.shape
+    hs, cs = [], []
+    for l in range(num_layers):
+        W, R = sd[f"{prefix}.weight_ih_l{l}"], sd[f"{prefix}.weight_hh_l{l}"]
+        b = sd[f"{prefix}.bias_ih_l{l}"] + sd[f"{prefix}.bias_hh_l{l}"]
+        H = R.shape[1]
+        h = x.new_zeros(B, H) if state is None else state[0][l]
+        c = x.new_zeros(B, H) if state is None else state[1][l]
+        pre_all = x @ W.t() + b
+        outs = []
+        for t in range(T):
+            pre = pre_all[t] + h @ R.t()
+            i, f, g, o = pre.split(H, dim=1)
+            c = torch.sigmoid(i) * torch.tanh(g) + torch.sigmoid(f) * c
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        x = torch.stack(outs, 0)
+        hs.append(h)
+        cs.append(c)
+    return x, (torch.stack(hs), torch.stack(cs))
+
+
+def stack_time(x, lens, factor):
+    T, B, H = x.shape
+    seq = [x]
+    for i in range(1, factor):
+        tmp = torch.zeros_like(x)
+        tmp[:-i] = x[i:]
+        seq.append(tmp)
+    return torch.cat(seq, 2)[::factor], (lens + factor - 1) // factor
+
+
+def encode(sd, cfg, x, x_lens):
+    x, _ = _lstm_stack(sd, "encoder.pre_rnn.lstm", x, cfg["enc_pre_rnn_layers"])
+    x, lens = stack_time(x, x_lens, cfg["enc_stack_time_factor"])
+    x, _ = _lstm_stack(sd, "encoder.post_rnn.lstm", x, cfg["enc_post_rnn_layers"])
+    return x.transpose(0, 1) @ sd["joint_enc.weight"].t() + sd["joint_enc.bias"], lens
+
+
+def predict(sd, cfg, y, state=None, add_sos=True):
+    e = sd["prediction.embed.weight"][y]  # [B,U,H]
+    if add_sos:
+        e = torch.cat([e.new_zeros(e.shape[0], 1, e.shape[2]), e], 1)
+    g, st = _lstm_stack(sd, "prediction.dec_rnn.lstm", e.transpose(0, 1), cfg["pred_rnn_layers"], state)
+    return g.transpose(0, 1) @ sd["joint_pred.weight"].t() + sd["joint_pred.bias"], st
+
+
+def joint(sd, f, g):
+    h = torch.relu(f.unsqueeze(2) + g.unsqueeze(1))
+    return h @ sd["joint_net.2.weight"].t() + sd["joint_net.2.bias"]
+
+
+def forward(sd, cfg, x, x_lens, y, y_lens):
+    """-> padded logits [B, T', U+1, V], f_lens."""
+    f, f_lens = encode(sd, cfg, x, x_lens)
+    g, _ = predict(sd, cfg, y)
+    return joint(sd, f, g), f_lens
+
+
+class OracleTransducerLoss(torch.autograd.Function):
+    """Per-utterance loss on PADDED logits via oracle/rnnt_oracle.c (float64)."""
+
+    @staticmethod
+    def forward(ctx, x, label, f_len, y_len, blank, mods):
+        xn = x.detach().double().numpy()
+        a, b, loss, denom = native.transducer_forward(xn, label.numpy(), f_len.numpy(), y_len.numpy(), blank, **mods)
+        ctx.pack = (xn, a, b, denom, label.numpy(), f_len.numpy(), y_len.numpy(), blank, mods)
+        return torch.from_numpy(loss).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gl):
+        xn, a, b, denom, label, f_len, y_len, blank, mods = ctx.pack
+        g = native.transducer_backward(xn, denom, gl.double().numpy(), a, b, label, f_len, y_len, blank, **mods)
+        return torch.from_numpy(g).to(gl.dtype), None, None, None, None, None
+
+
+def loss_and_grads(sd_np, cfg, x, x_lens, y, y_lens, blank, delay_penalty=0.0, eos_penalty=0.0, eos_idx=None,
+                   star_penalty=1.0, star_idx=None, dtype=torch.float64):
+    """Batch-mean loss and d loss / d every parameter (dict name -> ndarray)."""
+    sd = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in sd_np.items()}
+    logits, f_lens = forward(sd, cfg, torch.as_tensor(x, dtype=dtype), torch.as_tensor(x_lens),
+                             torch.as_tensor(y), torch.as_tensor(y_lens))
+    mods = dict(delay_penalty=delay_penalty, eos_penalty=eos_penalty, eos_idx=eos_idx,
+                star_lam=math.log(star_penalty), star_idx=star_idx)
+    per_utt = OracleTransducerLoss.apply(logits, torch.as_tensor(y).int(), f_lens.int(),
+                                         torch.as_tensor(y_lens).int(), blank, mods)
+    loss = per_utt.mean()
+    loss.backward()
+    return float(loss), {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}, logits.detach().numpy()
+
+
+def greedy_decode(sd, cfg, x, x_lens, blank, max_symbols_per_step=30, max_symbol_per_sample=None):
+    """Sequential per-utterance greedy search: the batched loop of
+    training/caiman_asr_train/rnnt/batched_greedy.py:59-199 unrolled for one stream at a time
+    (same stop rules, same never-reset-on-blank emission counter, :122-139,168-199).
+    -> (tokens, frames, confidences) per utterance."""
+    f, f_lens = encode(sd, cfg, x, x_lens)
+    toks, frames, confs = [], [], []
+    for b in range(f.shape[0]):
+        tk, fr, cf = [], [], []
+        g, st = predict(sd, cfg, torch.zeros(1, 0, dtype=torch.long))  # SOS: zero embedding, zero state
+        t, per_step, total = 0, 0, 0
+        last = int(f_lens[b]) - 1
+        while True:
+            logits = joint(sd, f[b:b + 1, t:t + 1], g[:, -1:])[0, 0, 0]
+            lp = torch.log_softmax(logits, -1)
+            k = int(torch.argmax(lp))
+            if t == last and k == blank:
+                break
+            if max_symbols_per_step is not None and t == last and per_step >= max_symbols_per_step:
+                break
+            if max_symbol_per_sample is not None and total >= max_symbol_per_sample:
+                break
+            nonblank = k != blank
+            if nonblank:
+                tk.append(k)
+                fr.append(t)
+                cf.append(float(lp[k].exp()))
+                total += 1
+            advance = not nonblank
+            if max_symbols_per_step is not None:
+                per_step += int(nonblank)
+                advance = advance or per_step >= max_symbols_per_step
+                if not (per_step < max_symbols_per_step or t == last):
+                    per_step = 0
+            t = min(t + int(advance), last)
+            if nonblank:
+                g, st = predict(sd, cfg, torch.tensor([[k]]), st, add_sos=False)
+        toks.append(tk)
+        frames.append(fr)
+        confs.append(cf)
+    return toks, frames, confs

@@ -1,0 +1,191 @@
+"""GPU parity at model level: the HIP-backed RNNT vs (a) outputs of the reference's own RNNT class
+(tests/golden, from oracle/gen_golden.py) and (b) the CPU oracle's loss and parameter gradients."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def load(tag):
+    g = np.load(os.path.join(GOLD, f"rnnt_{tag}.npz"))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    return g, sd, json.loads(str(g["cfg"]))
+
+
+def build(tag, **over):
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    g, sd, cfg = load(tag)
+    cfg = dict(cfg, custom_lstm=True, **over)
+    m = RNNT(n_classes=int(g["n_classes"]), **cfg)
+    m.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    return g, sd, cfg, m.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mfma"])
+def test_forward_matches_reference_fp32(tag):
+    g, sd, cfg, m = build(tag)
+    m.eval()
+    x, xl = torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV)
+    y, yl = torch.tensor(g["y"], device=DEV), torch.tensor(g["y_lens"], device=DEV)
+    with torch.no_grad():
+        f, fl, _ = m.encode(x, xl)
+        gg, _, _ = m.predict(y)
+        logits, out_lens, _ = m(x, xl, y, yl)
+    assert np.array_equal(fl.cpu().numpy(), g["f_lens"])
+    assert np.allclose(f.cpu().numpy(), g["f"], atol=5e-5)
+    assert np.allclose(gg.cpu().numpy(), g["g"], atol=5e-5)
+    assert np.allclose(logits.cpu().numpy(), g["logits"], atol=3e-4)
+
+
+def test_forward_bf16_autocast_close_to_reference():
+    g, sd, cfg, m = build("mfma")
+    m.eval()
+    x, xl = torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV)
+    y, yl = torch.tensor(g["y"], device=DEV), torch.tensor(g["y_lens"], device=DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        logits, _, _ = m(x, xl, y, yl)
+    assert logits.dtype == torch.bfloat16
+    ref = g["logits"]
+    err = np.abs(logits.float().cpu().numpy() - ref)
+    # 5 stacked LSTM layers in bf16 storage: loose, but far below the logit scale (~10)
+    assert err.max() < 0.12 * np.abs(ref).max() and err.mean() < 0.02 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("tag,joint", [("tiny", "pack"), ("tiny", "not_pack"), ("mfma", "pack")])
+def test_train_step_loss_and_all_parameter_grads_match_oracle(tag, joint):
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers, get_packing_meta_data
+    from oracle import model as omodel
+
+    g, sd, cfg, m = build(tag, joint_apex_transducer=joint, joint_apex_relu_dropout=True)
+    m.train()  # all dropout probabilities are 0 in the golden config
+    V = int(g["n_classes"])
+    x, xl = torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV)
+    y, yl = torch.tensor(g["y"], device=DEV), torch.tensor(g["y_lens"], device=DEV)
+    meta = get_packing_meta_data(xl, yl, 2)
+    logits, out_lens, _ = m(x, xl, y, yl, batch_offset=meta["batch_offset"])
+    loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=(joint == "pack"))
+    loss = loss_fn(logits, out_lens, y, yl, meta["batch_offset"], meta["max_f_len"],
+                   LossModifiers(delay_penalty=0.01, eos_penalty=0.0, star_penalty=1.0))
+    loss.backward()
+    ref_loss, ref_grads, ref_logits = omodel.loss_and_grads(sd, cfg, g["x"], g["x_lens"], g["y"], g["y_lens"], V - 1,
+                                                            delay_penalty=0.01)
+    assert loss.item() == pytest.approx(ref_loss, rel=2e-5)
+    if joint == "pack":
+        assert logits.dim() == 2 and logits.shape[0] == int(g["batch_offset"][-1])
+    got = dict(m.named_parameters())
+    for name, rg in ref_grads.items():
+        gg = got[name].grad
+        assert gg is not None, name
+        scale = max(np.abs(rg).max(), 1e-3)
+        assert np.allclose(gg.cpu().numpy(), rg, atol=3e-4 * scale + 2e-6), name
+
+
+def test_joint_pack_equals_broadcast_add_and_padding_is_minus_one():
+    # training/tests/rnnt/test_model.py:34-64
+    from caiman_asr_amd.rnnt.joint import TransducerJoint
+
+    torch.manual_seed(0)
+    B, T, U, H = 3, 7, 5, 24
+    f = torch.randn(B, T, H, device=DEV, requires_grad=True)
+    g = torch.randn(B, U, H, device=DEV, requires_grad=True)
+    f_len = torch.tensor([7, 4, 6], device=DEV)
+    g_len = torch.tensor([5, 5, 2], device=DEV)
+    ref = f.unsqueeze(2) + g.unsqueeze(1)
+    out = TransducerJoint(pack_output=False)(f, g, f_len, g_len)
+    bo = torch.cumsum(f_len * g_len, 0)
+    packed = TransducerJoint(pack_output=True)(f, g, f_len, g_len, batch_offset=bo, packed_batch=int(bo[-1]))
+    off = 0
+    for b in range(B):
+        t, u = int(f_len[b]), int(g_len[b])
+        assert torch.equal(out[b, :t, :u], ref[b, :t, :u])
+        assert (out[b, t:] == -1).all() and (out[b, :, u:] == -1).all()
+        assert torch.equal(packed[off:off + t * u].view(t, u, H), ref[b, :t, :u])
+        off += t * u
+    # gradients: sum over the valid region only
+    w = torch.randn_like(packed)
+    packed.backward(w)
+    f2, g2 = f.detach().clone().requires_grad_(True), g.detach().clone().requires_grad_(True)
+    ref2 = f2.unsqueeze(2) + g2.unsqueeze(1)
+    off, tot = 0, 0
+    for b in range(B):
+        t, u = int(f_len[b]), int(g_len[b])
+        tot = tot + (ref2[b, :t, :u] * w[off:off + t * u].view(t, u, H)).sum()
+        off += t * u
+    tot.backward()
+    assert torch.allclose(f.grad, f2.grad, atol=1e-5) and torch.allclose(g.grad, g2.grad, atol=1e-5)
+
+
+def test_joint_relu_dropout_semantics():
+    from caiman_asr_amd.rnnt.joint import TransducerJoint
+
+    torch.manual_seed(1)
+    B, T, U, H = 2, 6, 4, 64
+    f = torch.randn(B, T, H, device=DEV, requires_grad=True)
+    g = torch.randn(B, U, H, device=DEV, requires_grad=True)
+    fl, gl = torch.tensor([6, 6], device=DEV), torch.tensor([4, 4], device=DEV)
+    j = TransducerJoint(pack_output=False, relu=True, dropout=True, dropout_prob=0.3)
+    j.eval()  # dropout off in eval (test_model.py:67-104)
+    assert torch.equal(j(f, g, fl, gl), torch.relu(f.unsqueeze(2) + g.unsqueeze(1)))
+    j.train()
+    out = j(f, g, fl, gl)
+    ref = torch.relu(f.unsqueeze(2) + g.unsqueeze(1))
+    kept = out != 0
+    assert torch.allclose(out[kept], ref[kept] / 0.7, rtol=1e-6)
+    frac = 1 - kept[ref > 0].float().mean().item()
+    assert 0.25 < frac < 0.35  # ~30 % of the positive activations dropped
+    out.sum().backward()
+    # d/df = sum_u mask/(1-p)
+    assert torch.allclose(f.grad, (kept.float() / 0.7).sum(2), atol=1e-5)
+
+
+def test_lamb_step_matches_python_restatement():
+    from caiman_asr_amd.train_utils.optimizer import FusedLAMB
+
+    torch.manual_seed(0)
+    shapes = [(300, 70), (70,), (1, 5), (2000, 33)]
+    params = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    groups = [dict(params=params[:2], lr=4e-3), dict(params=params[2:], lr=4e-3 * 0.343)]
+    p0 = [p.detach().clone().double() for p in params]
+    opt = FusedLAMB(groups, lr=4e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_grad_norm=1.0,
+                    ema_decay=0.999)
+    m = [torch.zeros_like(p) for p in p0]
+    v = [torch.zeros_like(p) for p in p0]
+    ema = [p.clone() for p in p0]
+    lrs = [4e-3, 4e-3, 4e-3 * 0.343, 4e-3 * 0.343]
+    for step in range(1, 4):
+        grads = [torch.randn(s, device=DEV) * (3.0 if step == 1 else 0.01) for s in shapes]
+        for p, gr in zip(params, grads):
+            p.grad.copy_(gr)
+        opt.step(zero_grad=True)
+        gd = [gr.double() for gr in grads]
+        gnorm = torch.sqrt(sum((x ** 2).sum() for x in gd))
+        clip = gnorm / 1.0 if gnorm > 1.0 else 1.0
+        for i in range(len(p0)):
+            sg = gd[i] / clip
+            m[i] = 0.9 * m[i] + 0.1 * sg
+            v[i] = 0.999 * v[i] + 0.001 * sg * sg
+            upd = (m[i] / (1 - 0.9 ** step)) / (torch.sqrt(v[i] / (1 - 0.999 ** step)) + 1e-9) + 1e-2 * p0[i]
+            ratio = p0[i].norm() / upd.norm()
+            p0[i] = p0[i] - lrs[i] * ratio * upd
+            ema[i] = 0.999 * ema[i] + 0.001 * p0[i]
+        assert opt.grad_norm.item() == pytest.approx(gnorm.item(), rel=1e-5)
+        for i, p in enumerate(params):
+            assert torch.allclose(p.double(), p0[i], atol=2e-6, rtol=2e-5), (step, i)
+            assert (p.grad == 0).all()
+        for p, e in opt.ema_tensors().items():
+            i = [id(q) for q in params].index(id(p))
+            assert torch.allclose(e.double(), ema[i], atol=2e-6, rtol=2e-5)
+    # a non-finite gradient leaves parameters and moments untouched
+    before = [p.detach().clone() for p in params]
+    params[0].grad[0, 0] = float("nan")
+    opt.step()
+    assert opt.last_step_applied.item() == 0
+    for p, b in zip(params, before):
+        assert torch.equal(p, b)

@@ -1,0 +1,130 @@
+"""CPU tests of the host-side logic against golden data produced by the reference's own Python
+(oracle/gen_golden.py): constructor / state_dict schema, LR policy, shape ops, packing metadata."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cfg(name):
+    return json.load(open(os.path.join(GOLD, f"rnnt_cfg_{name}.json")))
+
+
+@pytest.mark.parametrize("name,n_classes,n_params", [("base", 8704, 84690432), ("large", 17408, 195590400)])
+def test_state_dict_schema_matches_reference(name, n_classes, n_params):
+    # training/caiman_asr_train/export/model_schema/{base,large}.json; 84.69 M / 195.59 M parameters
+    from caiman_asr_amd.rnnt import config
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    kw = config.validate_and_fill(RNNT, _cfg(name), optional=["n_classes"], deprecated=["hard_activation_functions"])
+    kw.pop("n_classes", None)
+    with torch.device("meta"):
+        m = RNNT(n_classes=n_classes, **kw)
+    schema = json.load(open(os.path.join(GOLD, f"schema_{name}.json")))
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert mine == schema
+    assert list(mine) == list(schema)  # same order
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    groups = m.param_groups(4e-3, return_module_name=True)
+    assert [g["module_name"] for g in groups] == ["encoder", "prediction", "joint_enc", "joint_pred", "joint_net"]
+    assert groups[-1]["lr"] == pytest.approx(4e-3 * _cfg(name)["joint_net_lr_factor"])
+
+
+def test_unknown_config_key_is_rejected():
+    from caiman_asr_amd.rnnt import config
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    bad = dict(_cfg("base"), not_a_key=1)
+    with pytest.raises(AssertionError, match="Unknown parameter"):
+        config.validate_and_fill(RNNT, bad)
+    ok = config.validate_and_fill(RNNT, dict(_cfg("base"), hard_activation_functions=False),
+                                  deprecated=["hard_activation_functions"], optional=["n_classes"])
+    assert "hard_activation_functions" not in ok
+
+
+def test_yaml_loader_expands_anchors(tmp_path):
+    from caiman_asr_amd.rnnt import config
+
+    p = tmp_path / "c.yaml"
+    p.write_text("a: &x {k: 1}\nb: *x\nc:\n  !!merge <<: *x\n  j: 2\nrnnt: {}\n")
+    cfg = config.load(str(p))
+    assert cfg["b"] == {"k": 1} and cfg["c"] == {"k": 1, "j": 2}
+    cfg["a"]["k"] = 5
+    assert cfg["b"]["k"] == 1  # deep copy, not an alias
+    empty = tmp_path / "e.yaml"
+    empty.write_text("")
+    with pytest.raises(ValueError):
+        config.load(str(empty))
+
+
+def test_lr_policy_matches_reference():
+    from caiman_asr_amd.train_utils.lr import lr_policy
+
+    g = json.load(open(os.path.join(GOLD, "lr_policy.json")))
+
+    class Opt:
+        param_groups = [dict(lr=0.0), dict(lr=0.0)]
+
+    for row in g["rows"]:
+        lr_policy(Opt, g["initial_lr"], g["min_lr"], row[0], g["warmup"], g["hold"], g["half_life"])
+        assert [pg["lr"] for pg in Opt.param_groups] == row[1:]  # exact: same float expression
+
+
+def test_stack_time_and_frame_splicing_match_reference():
+    from caiman_asr_amd.data.features import stack_subsample_frames
+    from caiman_asr_amd.rnnt.model import StackTime
+
+    g = np.load(os.path.join(GOLD, "shape_ops.npz"))
+    x, lens = torch.tensor(g["x"]), torch.tensor(g["lens"])
+    for fac in (2, 3):
+        o, l = StackTime(fac)(x, lens)
+        assert np.array_equal(o.numpy(), g[f"stack{fac}"]) and np.array_equal(l.numpy(), g[f"stack{fac}_lens"])
+    a, alens = torch.tensor(g["a"]), torch.tensor(g["alens"])
+    for s, ss in ((3, 3), (1, 1), (2, 1), (3, 2)):
+        o, l = stack_subsample_frames(a, alens, s, ss)
+        assert np.array_equal(o.numpy(), g[f"splice_{s}_{ss}"]), (s, ss)
+        assert np.array_equal(l.numpy(), g[f"splice_{s}_{ss}_lens"])
+
+
+def test_packing_metadata_matches_reference():
+    from caiman_asr_amd.rnnt.loss import get_packing_meta_data
+
+    g = np.load(os.path.join(GOLD, "rnnt_tiny.npz"))
+    meta = get_packing_meta_data(torch.tensor(g["x_lens"]), torch.tensor(g["y_lens"]), 2)
+    assert np.array_equal(meta["batch_offset"].numpy(), g["batch_offset"])
+    assert meta["max_f_len"] == int(g["max_f_len"]) and meta["packed_batch"] == int(g["batch_offset"][-1])
+
+
+def test_spec_augment_mask_statistics():
+    from caiman_asr_amd.data.features import SpecAugment
+
+    sa = SpecAugment(freq_masks=2, min_freq=0, max_freq=20, time_masks=10, min_time=0, max_time=0.03)
+    lens = torch.tensor([400, 200, 1000])
+    gen = torch.Generator().manual_seed(0)
+    m = sa.make_mask((3, 80, 1000), lens, torch.device("cpu"), generator=gen)
+    # at most 2 bands of <=20 bins; at most 10 spans of <= round(0.03*len) frames
+    for b in range(3):
+        assert m[b].all(1).sum() <= 40
+        assert m[b].all(0).sum() <= 10 * round(0.03 * int(lens[b]))
+    x = torch.randn(3, 80, 1000)
+    y, _ = sa.calculate_features(x, lens)
+    assert ((y == 0) | (y == x)).all()
+    assert SpecAugment().calculate_features(x, lens)[0].equal(x)
+
+
+def test_model_refuses_cpu_tensors_and_cpu_fallbacks():
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    cfg = json.loads(str(np.load(os.path.join(GOLD, "rnnt_tiny.npz"))["cfg"]))
+    cfg["custom_lstm"] = True
+    m = RNNT(n_classes=30, **cfg)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        m.encode(torch.randn(5, 2, cfg["in_feats"]), torch.tensor([5, 4]))
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        RNNT(n_classes=30, **dict(cfg, gpu_unavailable=True))
+    with pytest.raises(ValueError, match="quantize"):
+        RNNT(n_classes=30, **dict(cfg, quantize=True))
