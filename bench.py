@@ -46,7 +46,7 @@ def make_batches(n_batches, batch_size, seed, n_mels=80):
     ~3.3 tokens/s, sorted into 6 duration buckets like the reference's BucketingSampler; every batch
     is drawn from one bucket.  Returns host tensors: log-mel [B, 80, T], frame lens, tokens, token lens."""
     rng = np.random.default_rng(seed)
-    n_utts = n_batches * batch_size
+    n_utts = 6 * (n_batches // 6 + 2) * batch_size  # every bucket can serve its share of the batches
     dur = np.clip(rng.normal(12.3, 3.8, size=n_utts), 1.0, 16.7)
     order = np.argsort(dur)
     buckets = np.array_split(order, 6)
@@ -56,8 +56,7 @@ def make_batches(n_batches, batch_size, seed, n_mels=80):
     while len(batches) < n_batches:
         pool = per_bucket[bi % 6]
         bi += 1
-        if len(pool) < batch_size:
-            continue
+        assert len(pool) >= batch_size, "bucket pool exhausted"
         idx = [pool.pop() for _ in range(batch_size)]
         d = dur[idx]
         frames = np.floor(d * 100).astype(np.int64)  # 10 ms hop
@@ -89,7 +88,7 @@ def cpu_baseline(model, threads):
     omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, N_CLASSES - 1, dtype=torch.float32)  # warm-up
     t0 = time.perf_counter()
     iters = 0
-    while iters < 3 or (time.perf_counter() - t0 < 10 and iters < 50):
+    while iters < 2 or (time.perf_counter() - t0 < 10 and iters < 50):
         omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, N_CLASSES - 1, dtype=torch.float32)
         iters += 1
     dt = (time.perf_counter() - t0) / iters
@@ -102,7 +101,7 @@ def cpu_baseline(model, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,13 +169,20 @@ def main():
         optimizer.step(zero_grad=True)
         return loss.detach(), float(lens_h.sum()) * FRAME_SECONDS, meta["packed_batch"]
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model + {n_distinct} batches resident; warm-up")
     for i in range(args.warmup):
         last_loss, _, _ = step(i, i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
         if i == 0:
             loss_fn.t_loss.validate_lengths = False  # inputs validated once; no per-step host syncs
     barrier()
@@ -192,6 +198,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.timing.enabled = False
+    log(f"{args.steps} timed steps in {elapsed:.3f} s")
 
     stats = torch.tensor([elapsed, audio_s], dtype=torch.float64, device=dev)
     if world > 1:
@@ -231,7 +238,11 @@ def main():
                                    "avg_launch_ms": ms / n_launch, "launches": n_launch}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(model, threads=os.cpu_count() or 1)
+                # the box exposes more logical CPUs than this job's share (16 per GPU): oversubscribing
+                # torch's intra-op pool makes the CPU leg crawl
+                cores = min(16, len(os.sched_getaffinity(0)))
+                log(f"cpu_baseline on {cores} threads")
+                out["cpu_baseline"] = cpu_baseline(model, threads=cores)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -104,7 +104,7 @@ def loss_and_grads(sd_np, cfg, x, x_lens, y, y_lens, blank, delay_penalty=0.0, e
                                          torch.as_tensor(y_lens).int(), blank, mods)
     loss = per_utt.mean()
     loss.backward()
-    return float(loss), {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}, logits.detach().numpy()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}, logits.detach().numpy()
 
 
 def greedy_decode(sd, cfg, x, x_lens, blank, max_symbols_per_step=30, max_symbol_per_sample=None):
