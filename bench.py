@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,9 +193,15 @@ def main():
     audio_s, cells = 0.0, 0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ts = time.perf_counter()
         last_loss, a, c = step(args.warmup + i, args.warmup + i)
         audio_s += a
         cells += c
+        if args.debug_steps:
+            tl = time.perf_counter()
+            torch.cuda.synchronize()
+            log(f"step {i}: launch {1e3 * (tl - ts):.1f} ms, total {1e3 * (time.perf_counter() - ts):.1f} ms, "
+                f"audio {a:.0f} s, cells {c}")
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.timing.enabled = False

@@ -11,12 +11,12 @@
 // HBM in the gate dtype.  Here ONE launch per step does the 4-gate recurrent GEMM on
 // MFMA (bf16/f16 -> fp32 accumulate), reduces the split-K partials through LDS and
 // applies the cell update in fp32 before a single rounding to the storage dtype.
-//   fwd tile : 32 batch rows x (4 gates x 8 hidden units), v_mfma_f32_32x32x16, K = H
-//              split over the 4 waves of the workgroup; operands are read straight
-//              from L2 into registers (every element is used once per workgroup, so
-//              LDS staging would be pure overhead — guide §5 "GEMV / M<=16" row).
-//   bwd tile : 32 batch rows x 16 hidden units, v_mfma_f32_16x16x32, K = 4H split over
-//              8 waves, B operand from a once-per-call transposed copy of R.
+//   fwd tile : 32 batch rows x (4 gates x 4 hidden units), v_mfma_f32_16x16x32, K = H dealt
+//              round-robin to the 4 waves of the workgroup;
+//   bwd tile : 32 batch rows x 16 hidden units, K = 4H dealt to 16 waves;
+//   both read fragment-major ("tiled") operand images straight from L2 into registers (every
+//   element is used once per workgroup, so LDS staging would be pure overhead — guide §5
+//   "GEMV / M<=16" row); see the MFMA section below for the layout and the measurements.
 // A generic scalar kernel covers f32 / f64 and sizes the MFMA tiles do not divide.
 #include "common.h"
 
@@ -128,108 +128,223 @@ __global__ void lstm_bwd_step_generic(const T* __restrict__ R, const T* __restri
 }
 
 // ===========================================================================
-// MFMA forward step.  grid = (H/8, ceil(B/32)), 256 threads.
+// MFMA path (bf16 / f16, H % 32 == 0).
+//
+// Fragment-major ("tiled") operand images.  A v_mfma_f32_16x16x32 operand fragment is
+// 16 rows x 64 bytes; read from a row-major [rows, K] matrix whose row stride is 2-8 KB that
+// is 16 half-used cache lines per wave-instruction, all on one or two L2 channels.  Measured
+// on MI355X (tools/lstm_microbench.hip, tools/lstm_bwd_microbench.hip): 6.1 -> 4.8 us per
+// forward step and 13.0 -> 7.8 us per backward step from re-laying BOTH operands so that every
+// wave-instruction reads one contiguous 1 KB block:
+//   weights : tiled once per call into the workspace (they are constant over the time loop),
+//   h / dG  : each step's epilogue writes, next to the row-major result the caller keeps, a
+//             tiled copy [batch tile][k-step][32 rows][32] into a 2-deep ring that only the
+//             next step reads.
+// Every global load of a step (operands AND epilogue inputs) is issued before the first MFMA:
+// the step is latency-bound, so exactly one memory round trip is exposed.
+// Kernel boundaries (~1.5-2.5 us) are the per-timestep synchronisation on purpose: an in-launch
+// grid barrier costs 4+ us on this chip (MI355X_MICROARCH.md, barrier-xcd row).
 // ===========================================================================
-template <typename T, bool HARD>
-__global__ __launch_bounds__(256) void lstm_fwd_step_mfma(const T* __restrict__ R, T* __restrict__ g,
-                                                          const T* __restrict__ c0, T* __restrict__ c1,
-                                                          const T* __restrict__ y0, T* __restrict__ y1,
-                                                          int B, int H) {
-  using frag = typename frag8<T>::type;
-  __shared__ float tile[4][32][33];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = lane & 31, hh = lane >> 5;
-  const int j0 = blockIdx.x * 8, m0 = blockIdx.y * 32;
-  const int Kw = H >> 2;  // K range of this wave
-  const int kbase = wave * Kw + 8 * hh;
-  // B operand: column n = r of the tile <-> R row (gate = r>>3, unit = j0 + (r&7)), K-contiguous.
-  const T* Rrow = R + (int64_t)((r >> 3) * H + j0 + (r & 7)) * H + kbase;
-  const int brow = m0 + r;
-  const bool bvalid = brow < B;
-  const T* Arow = y0 + (int64_t)(bvalid ? brow : 0) * H + kbase;
-  f32x16 acc;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  const int nk = Kw >> 4;
-#pragma unroll 8
-  for (int s = 0; s < nk; ++s) {
-    frag a = *reinterpret_cast<const frag*>(Arow + 16 * s);
-    frag b = *reinterpret_cast<const frag*>(Rrow + 16 * s);
-    if (!bvalid) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] = static_cast<T>(0.f);
-    }
-    acc = mfma32(a, b, acc);
+
+// Rtile[((blk*nk + s)*16 + n)*32 + kk] = R[(gate(n)*H + blk*4 + unit(n))*H + s*32 + kk]
+template <typename T>
+__global__ __launch_bounds__(256) void tile_R_fwd_kernel(const T* __restrict__ R, T* __restrict__ out, int H) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)4 * H * H;
+  if (i >= total) return;
+  const int nk = H >> 5;
+  const int kk = (int)(i & 31);
+  const int n = (int)((i >> 5) & 15);
+  const int64_t rest = i >> 9;
+  const int s = (int)(rest % nk);
+  const int blk = (int)(rest / nk);
+  out[i] = R[(int64_t)((n >> 2) * H + blk * 4 + (n & 3)) * H + s * 32 + kk];
+}
+
+// Rttile[((blk*nk4 + s)*16 + n)*32 + kk] = R[(s*32 + kk)*H + blk*16 + n]   (nk4 = 4H/32)
+template <typename T>
+__global__ __launch_bounds__(256) void tile_Rt_bwd_kernel(const T* __restrict__ R, T* __restrict__ out, int H) {
+  __shared__ T t[32][17];
+  const int nk4 = (4 * H) >> 5;
+  const int s = blockIdx.x % nk4, blk = blockIdx.x / nk4;
+  // read R[s*32 + kk][blk*16 + n] : 32 rows x 16 cols
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int kk = e >> 4, n = e & 15;
+    t[kk][n] = R[(int64_t)(s * 32 + kk) * H + blk * 16 + n];
   }
-  // C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int q = 0; q < 16; ++q) tile[wave][(q & 3) + 8 * (q >> 2) + 4 * hh][r] = acc[q];
   __syncthreads();
-  const int eb = threadIdx.x >> 3, eu = threadIdx.x & 7;
-  const int b = m0 + eb, n = j0 + eu;
-  if (b >= B) return;
-  float pre[4];
-  const int64_t gb = (int64_t)b * 4 * H + n;
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int n = e >> 5, kk = e & 31;
+    out[((int64_t)blockIdx.x * 16 + n) * 32 + kk] = t[kk][n];
+  }
+}
+
+// rows [B, W] row-major -> tiled [ceil(B/32)][W/32][32][32]; padding rows are left untouched
+template <typename T>
+__global__ __launch_bounds__(256) void tile_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int W) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * W) return;
+  const int b = (int)(i / W), k = (int)(i % W);
+  dst[(((int64_t)(b >> 5) * (W >> 5) + (k >> 5)) * 32 + (b & 31)) * 32 + (k & 31)] = src[i];
+}
+
+__device__ __forceinline__ int64_t tiled_index(int b, int k, int nk) {
+  return (((int64_t)(b >> 5) * nk + (k >> 5)) * 32 + (b & 31)) * 32 + (k & 31);
+}
+
+// ---- forward step: grid (H/4, ceil(B/32)), 256 threads = 4 waves --------------------------
+//   output tile: 32 batch rows x 16 gate columns (4 gates x 4 hidden units); the H/32 k-steps
+//   are dealt round-robin to the 4 waves; NK = k-steps per wave (0 = runtime loop).
+template <typename T, bool HARD, int NK>
+__global__ __launch_bounds__(256) void lstm_fwd_step_mfma(const T* __restrict__ Rtile, T* __restrict__ g,
+                                                          const T* __restrict__ c0, T* __restrict__ c1,
+                                                          const T* __restrict__ h_in, T* __restrict__ y1,
+                                                          T* __restrict__ h_out, int B, int H) {
+  using frag = typename frag8<T>::type;
+  __shared__ float tile[4][2][16][17];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int j0 = blockIdx.x * 4, mt = blockIdx.y, m0 = mt * 32;
+  const int nk = H >> 5;
+
+  // epilogue inputs first: their latency hides under the operand loads
+  const int eb = tid >> 2, eu = tid & 3;
+  const int be = m0 + eb, ne = j0 + eu;
+  const bool ep = (tid < 128) && (be < B);
+  const int64_t gb = (int64_t)be * 4 * H + ne;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float cprev = 0.f;
+  if (ep) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre[q] = static_cast<float>(g[gb + (int64_t)q * H]);
+    cprev = static_cast<float>(c0[(int64_t)be * H + ne]);
+  }
+
+  const T* Bbase = Rtile + ((int64_t)blockIdx.x * nk * 16 + r) * 32 + 8 * kq;  // + s*512
+  const T* Abase = h_in + ((int64_t)mt * nk * 32 + r) * 32 + 8 * kq;           // + s*1024 (+512: rows 16..31)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (NK > 0) {
+    frag bf[NK], a0[NK], a1[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int s = wave + 4 * i;
+      const int sc = s < nk ? s : 0;  // NK*4 may exceed nk: clamp the address, zero the product below
+      bf[i] = *reinterpret_cast<const frag*>(Bbase + (int64_t)sc * 512);
+      a0[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024);
+      a1[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024 + 512);
+      if (s >= nk) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bf[i][q] = static_cast<T>(0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      acc0 = mfma16(a0[i], bf[i], acc0);
+      acc1 = mfma16(a1[i], bf[i], acc1);
+    }
+  } else {
+#pragma unroll 4
+    for (int s = wave; s < nk; s += 4) {
+      const frag bb = *reinterpret_cast<const frag*>(Bbase + (int64_t)s * 512);
+      const frag a0 = *reinterpret_cast<const frag*>(Abase + (int64_t)s * 1024);
+      const frag a1 = *reinterpret_cast<const frag*>(Abase + (int64_t)s * 1024 + 512);
+      acc0 = mfma16(a0, bb, acc0);
+      acc1 = mfma16(a1, bb, acc1);
+    }
+  }
+  // C layout 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int col = q * 8 + eu;
-    pre[q] = static_cast<float>(g[gb + (int64_t)q * H]) + tile[0][eb][col] + tile[1][eb][col] +
-             tile[2][eb][col] + tile[3][eb][col];
+    tile[wave][0][kq * 4 + q][r] = acc0[q];
+    tile[wave][1][kq * 4 + q][r] = acc1[q];
+  }
+  __syncthreads();
+  if (!ep) return;
+  const int half = eb >> 4, rr = eb & 15;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = q * 4 + eu;
+    pre[q] += tile[0][half][rr][col] + tile[1][half][rr][col] + tile[2][half][rr][col] + tile[3][half][rr][col];
   }
   const float i = Act<float, HARD>::sigm(pre[0]), f = Act<float, HARD>::sigm(pre[1]);
   const float gg = Act<float, HARD>::tanhv(pre[2]), o = Act<float, HARD>::sigm(pre[3]);
-  const float c = i * gg + f * static_cast<float>(c0[(int64_t)b * H + n]);
+  const float c = i * gg + f * cprev;
+  const T yv = static_cast<T>(o * Act<float, HARD>::tanhv(c));
+  h_out[tiled_index(be, ne, nk)] = yv;  // what the next step reads
+  y1[(int64_t)be * H + ne] = yv;
+  c1[(int64_t)be * H + ne] = static_cast<T>(c);
   g[gb] = static_cast<T>(i);
   g[gb + H] = static_cast<T>(f);
   g[gb + 2 * (int64_t)H] = static_cast<T>(gg);
   g[gb + 3 * (int64_t)H] = static_cast<T>(o);
-  c1[(int64_t)b * H + n] = static_cast<T>(c);
-  y1[(int64_t)b * H + n] = static_cast<T>(o * Act<float, HARD>::tanhv(c));
 }
 
-// ===========================================================================
-// MFMA backward step.  grid = (H/16, ceil(B/32)), 512 threads (8 waves, split-K over 4H).
-// Rt = Rᵀ, [H, 4H] row-major.
-// ===========================================================================
-template <typename T, bool HARD>
-__global__ __launch_bounds__(512) void lstm_bwd_step_mfma(const T* __restrict__ Rt, const T* __restrict__ g,
-                                                          const T* __restrict__ c_prev,
-                                                          const T* __restrict__ c_cur,
-                                                          const T* __restrict__ delta, int64_t d_sb,
-                                                          const T* __restrict__ dG_next, T* __restrict__ dG,
-                                                          float* __restrict__ dC, int B, int H) {
+// ---- backward step: grid (H/16, ceil(B/32)), 1024 threads = 16 waves ------------------------
+//   dh tile: 32 batch rows x 16 hidden units, K = 4H dealt round-robin to the 16 waves.
+template <typename T, bool HARD, int NK>
+__global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(const T* __restrict__ Rttile, const T* __restrict__ g,
+                                                           const T* __restrict__ c_prev,
+                                                           const T* __restrict__ c_cur,
+                                                           const T* __restrict__ delta, int64_t d_sb,
+                                                           const T* __restrict__ dG_in, T* __restrict__ dG,
+                                                           T* __restrict__ dG_out, float* __restrict__ dC, int B,
+                                                           int H) {
   using frag = typename frag8<T>::type;
-  __shared__ float tile[8][2][16][17];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
-  if (dG_next) {
+  __shared__ float tile[16][2][16][17];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n0 = blockIdx.x * 16, mt = blockIdx.y, m0 = mt * 32;
+  const int nk4 = (4 * H) >> 5;
+
+  const int eb = tid >> 4, eu = tid & 15;  // 32 rows x 16 units on the first 512 threads
+  const int be = m0 + eb, ne = n0 + eu;
+  const bool ep = (tid < 512) && (be < B);
+  const int64_t gb = (int64_t)be * 4 * H + ne;
+  float dy = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cp = 0.f, cc = 0.f, dcf = 0.f;
+  if (ep) {
+    dy = static_cast<float>(delta[(int64_t)be * d_sb + ne]);
+    gi = static_cast<float>(g[gb]);
+    gf = static_cast<float>(g[gb + H]);
+    gg = static_cast<float>(g[gb + 2 * (int64_t)H]);
+    go = static_cast<float>(g[gb + 3 * (int64_t)H]);
+    cp = static_cast<float>(c_prev[(int64_t)be * H + ne]);
+    cc = static_cast<float>(c_cur[(int64_t)be * H + ne]);
+    dcf = dC[(int64_t)be * H + ne];
+  }
+
+  if (dG_in) {
     const int r = lane & 15, kq = lane >> 4;
-    const int K = 4 * H, Kw = K >> 3;
-    const int kbase = wave * Kw + 8 * kq;
-    const T* Brow = Rt + (int64_t)(n0 + r) * K + kbase;
-    const int b0 = m0 + r, b1 = m0 + 16 + r;
-    const bool v0 = b0 < B, v1 = b1 < B;
-    const T* A0 = dG_next + (int64_t)(v0 ? b0 : 0) * K + kbase;
-    const T* A1 = dG_next + (int64_t)(v1 ? b1 : 0) * K + kbase;
+    const T* Bbase = Rttile + ((int64_t)blockIdx.x * nk4 * 16 + r) * 32 + 8 * kq;  // + s*512
+    const T* Abase = dG_in + ((int64_t)mt * nk4 * 32 + r) * 32 + 8 * kq;           // + s*1024 (+512)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int nk = Kw >> 5;
-#pragma unroll 4
-    for (int s = 0; s < nk; ++s) {
-      frag bb = *reinterpret_cast<const frag*>(Brow + 32 * s);
-      frag a0 = *reinterpret_cast<const frag*>(A0 + 32 * s);
-      frag a1 = *reinterpret_cast<const frag*>(A1 + 32 * s);
-      if (!v0) {
+    if constexpr (NK > 0) {
+      frag bf[NK], a0[NK], a1[NK];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a0[q] = static_cast<T>(0.f);
-      }
-      if (!v1) {
+      for (int i = 0; i < NK; ++i) {
+        const int s = wave + 16 * i;
+        const int sc = s < nk4 ? s : 0;
+        bf[i] = *reinterpret_cast<const frag*>(Bbase + (int64_t)sc * 512);
+        a0[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024);
+        a1[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024 + 512);
+        if (s >= nk4) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a1[q] = static_cast<T>(0.f);
+          for (int q = 0; q < 8; ++q) bf[i][q] = static_cast<T>(0.f);
+        }
       }
-      acc0 = mfma16(a0, bb, acc0);
-      acc1 = mfma16(a1, bb, acc1);
+#pragma unroll
+      for (int i = 0; i < NK; ++i) {
+        acc0 = mfma16(a0[i], bf[i], acc0);
+        acc1 = mfma16(a1[i], bf[i], acc1);
+      }
+    } else {
+#pragma unroll 2
+      for (int s = wave; s < nk4; s += 16) {
+        const frag bb = *reinterpret_cast<const frag*>(Bbase + (int64_t)s * 512);
+        const frag a0 = *reinterpret_cast<const frag*>(Abase + (int64_t)s * 1024);
+        const frag a1 = *reinterpret_cast<const frag*>(Abase + (int64_t)s * 1024 + 512);
+        acc0 = mfma16(a0, bb, acc0);
+        acc1 = mfma16(a1, bb, acc1);
+      }
     }
-    // C layout 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       tile[wave][0][kq * 4 + q][r] = acc0[q];
@@ -237,87 +352,117 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_mfma(const T* __restrict__ 
     }
   }
   __syncthreads();
-  const int eb = threadIdx.x >> 4, eu = threadIdx.x & 15;  // 32 rows x 16 units
-  const int b = m0 + eb, n = n0 + eu;
-  if (b >= B) return;
-  float dy = static_cast<float>(delta[(int64_t)b * d_sb + n]);
-  if (dG_next) {
-    const int mt = eb >> 4, rr = eb & 15;
+  if (!ep) return;
+  if (dG_in) {
+    const int half = eb >> 4, rr = eb & 15;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) dy += tile[w][mt][rr][eu];
+    for (int w = 0; w < 16; ++w) dy += tile[w][half][rr][eu];
   }
-  const int64_t gb = (int64_t)b * 4 * H + n;
-  const float i = static_cast<float>(g[gb]), f = static_cast<float>(g[gb + H]);
-  const float gg = static_cast<float>(g[gb + 2 * (int64_t)H]), o = static_cast<float>(g[gb + 3 * (int64_t)H]);
-  const float ct = Act<float, HARD>::tanhv(static_cast<float>(c_cur[(int64_t)b * H + n]));
-  const float dO = dy * ct * Act<float, HARD>::sigm_prime(o);
-  const float dc = dy * o * Act<float, HARD>::tanh_prime(ct) + dC[(int64_t)b * H + n];
-  dG[gb] = static_cast<T>(dc * gg * Act<float, HARD>::sigm_prime(i));
-  dG[gb + H] = static_cast<T>(dc * static_cast<float>(c_prev[(int64_t)b * H + n]) * Act<float, HARD>::sigm_prime(f));
-  dG[gb + 2 * (int64_t)H] = static_cast<T>(dc * i * Act<float, HARD>::tanh_prime(gg));
-  dG[gb + 3 * (int64_t)H] = static_cast<T>(dO);
-  dC[(int64_t)b * H + n] = dc * f;
-}
-
-// [rows, cols] -> [cols, rows], 32x32 LDS tiles.
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out,
-                                                        int rows, int cols) {
-  __shared__ T t[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  for (int k = ty; k < 32; k += 8)
-    if (r0 + k < rows && c0 + tx < cols) t[k][tx] = in[(int64_t)(r0 + k) * cols + c0 + tx];
-  __syncthreads();
-  for (int k = ty; k < 32; k += 8)
-    if (c0 + k < cols && r0 + tx < rows) out[(int64_t)(c0 + k) * rows + r0 + tx] = t[tx][k];
+  const float ct = Act<float, HARD>::tanhv(cc);
+  const float dc = dy * go * Act<float, HARD>::tanh_prime(ct) + dcf;
+  const T vI = static_cast<T>(dc * gg * Act<float, HARD>::sigm_prime(gi));
+  const T vF = static_cast<T>(dc * cp * Act<float, HARD>::sigm_prime(gf));
+  const T vG = static_cast<T>(dc * gi * Act<float, HARD>::tanh_prime(gg));
+  const T vO = static_cast<T>(dy * ct * Act<float, HARD>::sigm_prime(go));
+  if (dG_out) {  // tiled copy for the next (earlier-in-time) step
+    dG_out[tiled_index(be, ne, nk4)] = vI;
+    dG_out[tiled_index(be, H + ne, nk4)] = vF;
+    dG_out[tiled_index(be, 2 * H + ne, nk4)] = vG;
+    dG_out[tiled_index(be, 3 * H + ne, nk4)] = vO;
+  }
+  dG[gb] = vI;
+  dG[gb + H] = vF;
+  dG[gb + 2 * (int64_t)H] = vG;
+  dG[gb + 3 * (int64_t)H] = vO;
+  dC[(int64_t)be * H + ne] = dc * gf;
 }
 
 template <typename T>
 constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value;
 
+inline int64_t pad32(int64_t b) { return (b + 31) / 32 * 32; }
+
 template <typename T, bool HARD>
-int run_fwd(const T* R, T* gates, T* c, T* y, int64_t Tn, int64_t B, int64_t H, hipStream_t s) {
+int run_fwd(const T* R, T* gates, T* c, T* y, T* work, int64_t Tn, int64_t B, int64_t H, hipStream_t s) {
   const int64_t go = B * 4 * H, so = B * H;
   bool mfma = false;
-  if constexpr (kHasMfma<T>) mfma = (H % 64 == 0);
-  for (int64_t t = 0; t < Tn; ++t) {
-    T* g = gates + go * t;
-    if constexpr (kHasMfma<T>) {
-      if (mfma) {
-        hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD>), dim3((unsigned)(H / 8), (unsigned)((B + 31) / 32)),
-                           dim3(256), 0, s, R, g, c + so * t, c + so * (t + 1), y + so * t,
-                           y + so * (t + 1), (int)B, (int)H);
-        continue;
+  if constexpr (kHasMfma<T>) mfma = (H % 32 == 0) && work != nullptr;
+  if constexpr (kHasMfma<T>) {
+    if (mfma) {
+      T* Rtile = work;
+      T* hring = work + 4 * H * H;
+      const int64_t hsz = pad32(B) * H;
+      if (hipMemsetAsync(hring, 0, sizeof(T) * (size_t)(2 * hsz), s) != hipSuccess) return check_launch("lstm_fwd memset");
+      hipLaunchKernelGGL((tile_R_fwd_kernel<T>), dim3((unsigned)((4 * H * H + 255) / 256)), dim3(256), 0, s, R, Rtile, (int)H);
+      hipLaunchKernelGGL((tile_rows_kernel<T>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, y, hring, (int)B, (int)H);
+      const int nkw = (int)(((H >> 5) + 3) / 4);  // k-steps per wave
+      const dim3 grid((unsigned)(H / 4), (unsigned)((B + 31) / 32));
+      for (int64_t t = 0; t < Tn; ++t) {
+        T* hin = hring + (t & 1) * hsz;
+        T* hout = hring + ((t + 1) & 1) * hsz;
+#define CAIMAN_FWD(NKV)                                                                                       \
+  hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD, NKV>), grid, dim3(256), 0, s, Rtile, gates + go * t,        \
+                     c + so * t, c + so * (t + 1), hin, y + so * (t + 1), hout, (int)B, (int)H)
+        switch (nkw) {
+          case 1: CAIMAN_FWD(1); break;
+          case 2: CAIMAN_FWD(2); break;
+          case 4: CAIMAN_FWD(4); break;
+          case 6: CAIMAN_FWD(6); break;
+          case 8: CAIMAN_FWD(8); break;
+          case 12: CAIMAN_FWD(12); break;
+          default: CAIMAN_FWD(0); break;
+        }
+#undef CAIMAN_FWD
       }
+      return check_launch("caiman_lstm_fused_fwd");
     }
-    hipLaunchKernelGGL((lstm_fwd_step_generic<T, HARD>), dim3((unsigned)((H + 63) / 64), (unsigned)B), dim3(64),
-                       0, s, R, g, c + so * t, c + so * (t + 1), y + so * t, y + so * (t + 1), (int)B, (int)H);
   }
+  for (int64_t t = 0; t < Tn; ++t)
+    hipLaunchKernelGGL((lstm_fwd_step_generic<T, HARD>), dim3((unsigned)((H + 63) / 64), (unsigned)B), dim3(64),
+                       0, s, R, gates + go * t, c + so * t, c + so * (t + 1), y + so * t, y + so * (t + 1), (int)B,
+                       (int)H);
   return check_launch("caiman_lstm_fused_fwd");
 }
 
 template <typename T, bool HARD>
 int run_bwd(const T* R, const T* gates, const T* c, const T* delta, int64_t d_st, int64_t d_sb, T* dG,
-            acc_t<T>* dC, T* Rt, int64_t Tn, int64_t B, int64_t H, hipStream_t s) {
+            acc_t<T>* dC, T* work, int64_t Tn, int64_t B, int64_t H, hipStream_t s) {
   const int64_t go = B * 4 * H, so = B * H;
   if (hipMemsetAsync(dC, 0, sizeof(acc_t<T>) * (size_t)so, s) != hipSuccess) return check_launch("lstm_bwd memset");
   bool mfma = false;
-  if constexpr (kHasMfma<T>) mfma = (H % 64 == 0) && Rt != nullptr;
-  if (mfma && Tn > 1) {
-    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((H + 31) / 32), (unsigned)((4 * H + 31) / 32)),
-                       dim3(256), 0, s, R, Rt, (int)(4 * H), (int)H);
+  if constexpr (kHasMfma<T>) mfma = (H % 32 == 0) && work != nullptr;
+  if constexpr (kHasMfma<T>) {
+    if (mfma) {
+      T* Rttile = work;
+      T* dring = work + 4 * H * H;
+      const int64_t dsz = pad32(B) * 4 * H;
+      if (Tn > 1) {
+        if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * dsz), s) != hipSuccess) return check_launch("lstm_bwd memset");
+        hipLaunchKernelGGL((tile_Rt_bwd_kernel<T>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
+      }
+      const int nkw = (int)(((4 * H >> 5) + 15) / 16);
+      const dim3 grid((unsigned)(H / 16), (unsigned)((B + 31) / 32));
+      for (int64_t t = Tn - 1; t >= 0; --t) {
+        const T* din = (t < Tn - 1) ? dring + ((t + 1) & 1) * dsz : nullptr;
+        T* dout = (t > 0) ? dring + (t & 1) * dsz : nullptr;
+#define CAIMAN_BWD(NKV)                                                                                       \
+  hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD, NKV>), grid, dim3(1024), 0, s, Rttile, gates + go * t,      \
+                     c + so * t, c + so * (t + 1), delta + d_st * t, d_sb, din, dG + go * t, dout, dC, (int)B, (int)H)
+        switch (nkw) {
+          case 1: CAIMAN_BWD(1); break;
+          case 2: CAIMAN_BWD(2); break;
+          case 4: CAIMAN_BWD(4); break;
+          case 6: CAIMAN_BWD(6); break;
+          case 8: CAIMAN_BWD(8); break;
+          default: CAIMAN_BWD(0); break;
+        }
+#undef CAIMAN_BWD
+      }
+      return check_launch("caiman_lstm_fused_bwd");
+    }
   }
   for (int64_t t = Tn - 1; t >= 0; --t) {
     const T* dgn = (t < Tn - 1) ? dG + go * (t + 1) : nullptr;
-    if constexpr (kHasMfma<T>) {
-      if (mfma) {
-        hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD>), dim3((unsigned)(H / 16), (unsigned)((B + 31) / 32)),
-                           dim3(512), 0, s, Rt, gates + go * t, c + so * t, c + so * (t + 1),
-                           delta + d_st * t, d_sb, dgn, dG + go * t, dC, (int)B, (int)H);
-        continue;
-      }
-    }
     hipLaunchKernelGGL((lstm_bwd_step_generic<T, HARD>), dim3((unsigned)((H + 63) / 64), (unsigned)B), dim3(64),
                        0, s, R, gates + go * t, c + so * t, c + so * (t + 1), delta + d_st * t, d_sb, dgn,
                        dG + go * t, dC, (int)B, (int)H);
@@ -328,8 +473,14 @@ int run_bwd(const T* R, const T* gates, const T* c, const T* delta, int64_t d_st
 }  // namespace
 }  // namespace caiman
 
-extern "C" int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* y, int64_t T, int64_t B,
-                                     int64_t H, int dtype, int hard, caiman_stream_t stream) {
+extern "C" int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backward) {
+  if (B < 1 || H < 1) return 0;
+  const int64_t bp = (B + 31) / 32 * 32;
+  return 4 * H * H + 2 * bp * (backward ? 4 * H : H);
+}
+
+extern "C" int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* y, void* work, int64_t T,
+                                     int64_t B, int64_t H, int dtype, int hard, caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(T >= 0 && B >= 1 && H >= 1, "lstm_fused_fwd: bad extents T=%lld B=%lld H=%lld", (long long)T,
                (long long)B, (long long)H);
@@ -342,14 +493,15 @@ extern "C" int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* 
     auto gp = static_cast<scalar_t*>(gates);
     auto cp = static_cast<scalar_t*>(c);
     auto yp = static_cast<scalar_t*>(y);
-    return hard ? run_fwd<scalar_t, true>(Rp, gp, cp, yp, T, B, H, s)
-                : run_fwd<scalar_t, false>(Rp, gp, cp, yp, T, B, H, s);
+    auto wp = static_cast<scalar_t*>(work);
+    return hard ? run_fwd<scalar_t, true>(Rp, gp, cp, yp, wp, T, B, H, s)
+                : run_fwd<scalar_t, false>(Rp, gp, cp, yp, wp, T, B, H, s);
   });
 }
 
 extern "C" int caiman_lstm_fused_bwd(const void* R, const void* gates, const void* c, const void* delta,
                                      int64_t delta_stride_t, int64_t delta_stride_b, void* dG, void* dC,
-                                     void* Rt, int64_t T, int64_t B, int64_t H, int dtype, int hard,
+                                     void* work, int64_t T, int64_t B, int64_t H, int dtype, int hard,
                                      caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(T >= 0 && B >= 1 && H >= 1, "lstm_fused_bwd: bad extents T=%lld B=%lld H=%lld", (long long)T,
@@ -366,7 +518,7 @@ extern "C" int caiman_lstm_fused_bwd(const void* R, const void* gates, const voi
     auto dp = static_cast<const scalar_t*>(delta);
     auto dGp = static_cast<scalar_t*>(dG);
     auto dCp = static_cast<A*>(dC);
-    auto Rtp = static_cast<scalar_t*>(Rt);
+    auto Rtp = static_cast<scalar_t*>(work);
     return hard ? run_bwd<scalar_t, true>(Rp, gp, cp, dp, delta_stride_t, delta_stride_b, dGp, dCp, Rtp, T, B, H, s)
                 : run_bwd<scalar_t, false>(Rp, gp, cp, dp, delta_stride_t, delta_stride_b, dGp, dCp, Rtp, T, B, H, s);
   });

@@ -5,6 +5,23 @@ import torch
 from caiman_asr_amd import _lib
 
 
+_WORK = {}
+
+
+def _workspace(B, H, dtype, device, backward):
+    """Scratch for the MFMA path (tiled weights + operand ring), cached per shape: the kernels of
+    one stream run in order, so consecutive layers can reuse it."""
+    if dtype not in (torch.float16, torch.bfloat16) or H % 32 != 0:
+        return None
+    n = _lib.lib().caiman_lstm_workspace_elems(B, H, int(backward))
+    key = (device, dtype, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WORK.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=dtype, device=device)
+        _WORK[key] = buf
+    return buf
+
+
 def _dims(c):
     # lstm.cu:226-228: c is [T+1, B, H] or [T+1, H]
     if c.dim() == 3:
@@ -22,10 +39,11 @@ def _fwd(R, gates, c, y, hard):
     if R.shape != (4 * H, H) or gates.numel() != T * B * 4 * H or c.size(0) != T + 1 or y.shape != c.shape:
         raise RuntimeError(f"inconsistent LSTM shapes R{list(R.shape)} gates{list(gates.shape)} "
                            f"c{list(c.shape)} y{list(y.shape)}")
+    work = _workspace(B, H, gates.dtype, gates.device, False)
     with _lib.timed("lstm_fwd"):
         _lib.check(_lib.lib().caiman_lstm_fused_fwd(
-            _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(y), T, B, H, _lib.dtype_tag(gates.dtype),
-            int(hard), _lib.stream()))
+            _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(y), _lib.ptr(work) if work is not None else None,
+            T, B, H, _lib.dtype_tag(gates.dtype), int(hard), _lib.stream()))
 
 
 def _bwd(R, gates, c, delta, dG, hard):
@@ -41,12 +59,11 @@ def _bwd(R, gates, c, delta, dG, hard):
     if d.stride(2) != 1 and H > 1:
         d = d.contiguous()  # the reference always copies (lstm.cu:394-396)
     dC = torch.empty((B, H), dtype=_lib.acc_dtype(gates.dtype), device=gates.device)
-    use_rt = gates.dtype in (torch.float16, torch.bfloat16) and H % 64 == 0
-    Rt = torch.empty((H, 4 * H), dtype=R.dtype, device=R.device) if use_rt else None
+    work = _workspace(B, H, gates.dtype, gates.device, True)
     with _lib.timed("lstm_bwd"):
         _lib.check(_lib.lib().caiman_lstm_fused_bwd(
             _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(d), d.stride(0), d.stride(1), _lib.ptr(dG),
-            _lib.ptr(dC), _lib.ptr(Rt) if Rt is not None else None, T, B, H, _lib.dtype_tag(gates.dtype),
+            _lib.ptr(dC), _lib.ptr(work) if work is not None else None, T, B, H, _lib.dtype_tag(gates.dtype),
             int(hard), _lib.stream()))
 
 

@@ -107,9 +107,15 @@ int caiman_transducer_loss_backward(
  * hard   : 0 = sigmoid/tanh, 1 = hard-sigmoid/hard-tanh (lstm.cu:41-76)
  * All tensors share `dtype`. Math is done in the accumulate type.
  * ------------------------------------------------------------------------- */
-int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* y, int64_t T,
-                          int64_t B, int64_t H, int dtype, int hard,
+int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* y, void* work,
+                          int64_t T, int64_t B, int64_t H, int dtype, int hard,
                           caiman_stream_t stream);
+
+/* Scratch the MFMA path needs, in ELEMENTS of `dtype` (forward: backward = 0):
+ *   4H*H (weights re-laid fragment-major once per call) + a 2-deep ring of the per-step
+ *   operand (h: pad32(B)*H, dG: pad32(B)*4H).  `work` may be NULL: the scalar kernels are
+ *   used then (correct for every dtype / size, but not fast).  f32 / f64 never need it. */
+int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backward);
 
 /* delta : upstream gradient w.r.t. y[1..T], [T, B, H] addressed with explicit element
  *         strides (unit stride on H). It is read-only: the reference first copies it to a
@@ -117,10 +123,10 @@ int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* y, int64_t 
  *         (lstm.cu:325-333,394-396); here the sum is formed in registers instead.
  * dG    : [T, B, 4H] out (gradient w.r.t. the PRE-activation gates)
  * dC    : [B, H] scratch in the ACCUMULATE type, zeroed by the callee (lstm.cu:298)
- * Rt    : [H, 4H] scratch (may be NULL: scalar path); the callee fills it with Rᵀ. */
+ * work  : see caiman_lstm_workspace_elems(B, H, 1); may be NULL. */
 int caiman_lstm_fused_bwd(const void* R, const void* gates, const void* c, const void* delta,
                           int64_t delta_stride_t, int64_t delta_stride_b, void* dG, void* dC,
-                          void* Rt, int64_t T, int64_t B, int64_t H, int dtype, int hard,
+                          void* work, int64_t T, int64_t B, int64_t H, int dtype, int hard,
                           caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
