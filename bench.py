@@ -233,16 +233,25 @@ def main():
         if not args.no_kernel_timing:
             summ = _lib.timing_summary()
             out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in summ.items()}
-            # Roofline of the fused transducer-loss backward (HBM-bound): algorithmic bytes per cell
-            # = V*s read + V*s write ; one launch per step covers every packed cell.
-            if "loss_bwd" in summ:
-                n_launch, ms = summ["loss_bwd"]
-                alg_bytes = cells * N_CLASSES * 2 * 2
-                achieved = alg_bytes / (ms * 1e-3) / 1e9
-                out["roofline"] = {"kernel": "loss_bwd_kernel (transducer loss fused backward)", "bound": "hbm",
-                                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # Roofline of the dominant kernel (profiles/: lstm_bwd_step_mfma, ~35 % of GPU time): one
+            # launch = one backward timestep of one LSTM layer. HBM-bound by construction: the
+            # recurrent weights are re-streamed every step because L2 does not survive a kernel
+            # boundary. Algorithmic bytes per launch: rnnt_ext/cuda/lstm.py::_step_bytes.
+            if "lstm_bwd" in summ:
+                _, ms, launches, nbytes = summ["lstm_bwd"]
+                achieved = nbytes / (ms * 1e-3) / 1e9
+                out["roofline"] = {"kernel": "lstm_bwd_step_mfma (one backward LSTM timestep per launch)",
+                                   "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                   "avg_launch_ms": ms / n_launch, "launches": n_launch}
+                                   "avg_launch_us": ms * 1e3 / launches, "launches": launches,
+                                   "algorithmic_bytes_per_launch": nbytes / launches}
+            if "loss_bwd" in summ:
+                n_launch, ms = summ["loss_bwd"][0], summ["loss_bwd"][1]
+                alg = cells * N_CLASSES * 2 * 2  # V*s read + V*s write per lattice cell
+                out["roofline_loss_bwd"] = {"kernel": "loss_bwd_kernel", "bound": "hbm",
+                                            "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "avg_launch_ms": ms / n_launch, "launches": n_launch}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # the box exposes more logical CPUs than this job's share (16 per GPU): oversubscribing

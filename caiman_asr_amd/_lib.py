@@ -179,10 +179,12 @@ class timed:
     """`with timed("name"):` brackets the enclosed launches with HIP events on the CURRENT stream
     (the stream the kernels are launched on) when timing is enabled; otherwise it is free."""
 
-    __slots__ = ("name", "start")
+    __slots__ = ("name", "start", "units", "nbytes")
 
-    def __init__(self, name):
+    def __init__(self, name, units=1, nbytes=0):
         self.name = name
+        self.units = units      # kernel launches of the dominant kernel inside the bracket
+        self.nbytes = nbytes    # algorithmic bytes moved inside the bracket
 
     def __enter__(self):
         if timing.enabled:
@@ -194,11 +196,12 @@ class timed:
         if timing.enabled:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
-            timing.records.setdefault(self.name, []).append((self.start, end))
+            timing.records.setdefault(self.name, []).append((self.start, end, self.units, self.nbytes))
         return False
 
 
 def timing_summary():
-    """{name: (calls, total_ms)}; synchronises."""
+    """{name: (calls, total_ms, kernel launches, algorithmic bytes)}; synchronises."""
     torch.cuda.synchronize()
-    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in timing.records.items()}
+    return {k: (len(v), sum(r[0].elapsed_time(r[1]) for r in v), sum(r[2] for r in v), sum(r[3] for r in v))
+            for k, v in timing.records.items()}

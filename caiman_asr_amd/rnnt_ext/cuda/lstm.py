@@ -22,6 +22,14 @@ def _workspace(B, H, dtype, device, backward):
     return buf
 
 
+def _step_bytes(B, H, es, backward):
+    """Algorithmic HBM bytes of ONE recurrent step: the recurrent weights
+    (not resident across kernel boundaries) + every per-step operand once."""
+    if backward:  # R + dG[t+1] in + gates + c[t], c[t+1] + delta + dG[t] out ; dC (f32) in/out
+        return 4 * H * H * es + B * (4 * H + 4 * H + 2 * H + H + 4 * H) * es + 2 * B * H * 4
+    return 4 * H * H * es + B * (H + 4 * H + H + 4 * H + 2 * H) * es  # R + h in + gates in/out + c in/out + y out
+
+
 def _dims(c):
     # lstm.cu:226-228: c is [T+1, B, H] or [T+1, H]
     if c.dim() == 3:
@@ -40,7 +48,7 @@ def _fwd(R, gates, c, y, hard):
         raise RuntimeError(f"inconsistent LSTM shapes R{list(R.shape)} gates{list(gates.shape)} "
                            f"c{list(c.shape)} y{list(y.shape)}")
     work = _workspace(B, H, gates.dtype, gates.device, False)
-    with _lib.timed("lstm_fwd"):
+    with _lib.timed("lstm_fwd", T, T * _step_bytes(B, H, gates.element_size(), False)):
         _lib.check(_lib.lib().caiman_lstm_fused_fwd(
             _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(y), _lib.ptr(work) if work is not None else None,
             T, B, H, _lib.dtype_tag(gates.dtype), int(hard), _lib.stream()))
@@ -60,7 +68,7 @@ def _bwd(R, gates, c, delta, dG, hard):
         d = d.contiguous()  # the reference always copies (lstm.cu:394-396)
     dC = torch.empty((B, H), dtype=_lib.acc_dtype(gates.dtype), device=gates.device)
     work = _workspace(B, H, gates.dtype, gates.device, True)
-    with _lib.timed("lstm_bwd"):
+    with _lib.timed("lstm_bwd", T, T * _step_bytes(B, H, gates.element_size(), True)):
         _lib.check(_lib.lib().caiman_lstm_fused_bwd(
             _lib.ptr(R), _lib.ptr(gates), _lib.ptr(c), _lib.ptr(d), d.stride(0), d.stride(1), _lib.ptr(dG),
             _lib.ptr(dC), _lib.ptr(work) if work is not None else None, T, B, H, _lib.dtype_tag(gates.dtype),
