@@ -1,0 +1,198 @@
+// Log-mel frontend on gfx950: pad -> dither -> pre-emphasis -> Hann frames -> 512-pt FFT power ->
+// mel filterbank -> ln, and the (blended) per-feature normalisation.
+//
+// Replaces the third-party DALI operator chain the reference drives on this path
+// (training/caiman_asr_train/data/dali/pipeline.py:260-315 construction, :439-462 graph tail;
+// normalisation training/caiman_asr_train/data/dali/mel_normalization.py:103-118).  DALI is not
+// vendored under /root/reference; operator semantics are restated from its documentation
+//  and the golden tensor of the reference's own test
+// (training/tests/data/dali/test_data_loader.py:235-258) is the intended pin.
+//
+// One wave64 per frame (8 frames per workgroup): the frame is windowed into LDS in bit-reversed
+// order, 9 radix-2 stages run in LDS, lanes 0..nmel-1 then each fold one triangular filter.
+// Window, twiddles and filter weights are tables built once on the host in double precision.
+#include "common.h"
+
+namespace caiman {
+namespace {
+
+constexpr int kFramesPerBlock = 8;
+
+__device__ __forceinline__ float gauss_from(uint64_t seed, uint64_t idx) {
+  // counter-based N(0,1): two splitmix64 uniforms -> Box-Muller
+  auto mix = [](uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  const uint64_t a = mix(seed + 0x9E3779B97F4A7C15ull * (2 * idx + 1));
+  const uint64_t b = mix(seed + 0x9E3779B97F4A7C15ull * (2 * idx + 2));
+  const float u1 = ((float)(a >> 40) + 1.0f) * (1.0f / 16777217.0f);  // (0,1]
+  const float u2 = (float)(b >> 40) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+struct MelParams {
+  const float* audio;       // [B, max_samples]
+  const int32_t* audio_len; // [B]
+  const float* window;      // [win_len]
+  const float* tw_cos;      // [nfft/2]
+  const float* tw_sin;      // [nfft/2]
+  const float* mel_w;       // [nmel, nfft/2+1] dense
+  const int32_t* mel_lo;    // [nmel] first bin with non-zero weight
+  const int32_t* mel_hi;    // [nmel] one past the last
+  int64_t B, max_samples, max_frames;
+  int win_len, hop, nfft, log2_nfft, nmel, pad;
+  float preemph, dither, log_floor;
+  uint64_t seed;
+};
+
+template <int NFFT>
+__global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParams p, float* __restrict__ out,
+                                                                        int32_t* __restrict__ out_len) {
+  __shared__ float re[kFramesPerBlock][NFFT];
+  __shared__ float im[kFramesPerBlock][NFFT];
+  const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  const int b = blockIdx.y;
+  const int64_t frame = (int64_t)blockIdx.x * kFramesPerBlock + w;
+  const int64_t n = p.audio_len[b];
+  const int64_t total = n + p.pad;  // padded signal length
+  const int64_t nframes = total >= p.win_len ? (total - p.win_len) / p.hop + 1 : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_len[b] = (int32_t)nframes;
+  const bool live = frame < nframes;
+  const float* x = p.audio + (int64_t)b * p.max_samples;
+
+  auto sample = [&](int64_t q) -> float {  // padded + dithered signal at padded index q (clamped at 0)
+    if (q < 0) q = 0;                      // PreemphasisFilter border = clamp
+    float v = (q >= p.pad && q - p.pad < n) ? x[q - p.pad] : 0.f;
+    if (p.dither != 0.f) v += p.dither * gauss_from(p.seed, (uint64_t)b * (uint64_t)(p.max_samples + p.pad) + (uint64_t)q);
+    return v;
+  };
+
+  // ---- window into LDS, bit-reversed -----------------------------------------------------------
+  for (int i = lane; i < NFFT; i += kWave) {
+    float v = 0.f;
+    if (live && i < p.win_len) {
+      const int64_t q = frame * p.hop + i;
+      v = (sample(q) - p.preemph * sample(q - 1)) * p.window[i];
+    }
+    const int j = __brev((unsigned)i) >> (32 - p.log2_nfft);
+    re[w][j] = v;
+    im[w][j] = 0.f;
+  }
+  __syncthreads();
+  // ---- radix-2 DIT --------------------------------------------------------------------------
+  for (int s = 0; s < p.log2_nfft; ++s) {
+    const int half = 1 << s;
+    const int tstride = NFFT >> (s + 1);
+    for (int k = lane; k < NFFT / 2; k += kWave) {
+      const int grp = k >> s, pos = k & (half - 1);
+      const int i0 = (grp << (s + 1)) + pos, i1 = i0 + half;
+      const float c = p.tw_cos[pos * tstride], sn = p.tw_sin[pos * tstride];  // e^{-2 pi i pos / (2 half)}
+      const float ar = re[w][i0], ai = im[w][i0], br = re[w][i1], bi = im[w][i1];
+      const float tr = br * c + bi * sn, ti = bi * c - br * sn;
+      re[w][i0] = ar + tr; im[w][i0] = ai + ti;
+      re[w][i1] = ar - tr; im[w][i1] = ai - ti;
+    }
+    __syncthreads();
+  }
+  // ---- power spectrum (bins 0..NFFT/2) into re[] ---------------------------------------------------
+  float pw[(NFFT / 2 + kWave) / kWave];
+#pragma unroll
+  for (int q = 0; q < (NFFT / 2 + kWave) / kWave; ++q) {
+    const int k = lane + q * kWave;
+    pw[q] = (k <= NFFT / 2) ? re[w][k] * re[w][k] + im[w][k] * im[w][k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < (NFFT / 2 + kWave) / kWave; ++q) {
+    const int k = lane + q * kWave;
+    if (k <= NFFT / 2) re[w][k] = pw[q];
+  }
+  __syncthreads();
+  // ---- mel + log ----------------------------------------------------------------------------------
+  if (frame < p.max_frames) {
+    const int nb = NFFT / 2 + 1;
+    for (int m = lane; m < p.nmel; m += kWave) {
+      float acc = 0.f;
+      if (live) {
+        const float* wrow = p.mel_w + (int64_t)m * nb;
+        for (int k = p.mel_lo[m]; k < p.mel_hi[m]; ++k) acc += wrow[k] * re[w][k];
+        acc = logf(fmaxf(acc, p.log_floor));
+      }
+      out[((int64_t)b * p.nmel + m) * p.max_frames + frame] = live ? acc : 0.f;  // Pad: fill 0
+    }
+  }
+}
+
+// (x - mean)/std over the valid frames of each (utterance, mel bin) row, optionally blended with
+// dataset statistics: r*(x-mu_d)/sd_d + (1-r)*(x-mu_u)/sd_u.  Population std (ddof = 0).
+__global__ __launch_bounds__(256) void mel_normalize_kernel(float* __restrict__ x, const int32_t* __restrict__ len,
+                                                            int64_t T, int nmel, const float* __restrict__ ds_mean,
+                                                            const float* __restrict__ ds_std, float ratio) {
+  __shared__ double sm[256 / kWave];
+  const int b = blockIdx.y, m = blockIdx.x;
+  float* row = x + ((int64_t)b * nmel + m) * T;
+  const int64_t n = len[b];
+  double s = 0;
+  for (int64_t t = threadIdx.x; t < n; t += 256) s += row[t];
+  s = block_reduce<256 / kWave>(s, [](double a, double c) { return a + c; }, sm);
+  const double mean = n > 0 ? s / (double)n : 0.0;
+  double v = 0;
+  for (int64_t t = threadIdx.x; t < n; t += 256) { const double d = row[t] - mean; v += d * d; }
+  v = block_reduce<256 / kWave>(v, [](double a, double c) { return a + c; }, sm);
+  const float sd = n > 0 ? (float)sqrt(v / (double)n) : 1.f;
+  const float mu = (float)mean;
+  const float r = ds_mean ? ratio : 0.f;
+  const float dm = ds_mean ? ds_mean[m] : 0.f, dsd = ds_std ? ds_std[m] : 1.f;
+  for (int64_t t = threadIdx.x; t < T; t += 256) {
+    if (t < n) {
+      const float xv = row[t];
+      float o = 0.f;
+      if (r < 1.f) o += (1.f - r) * (xv - mu) / sd;
+      if (r > 0.f) o += r * (xv - dm) / dsd;
+      row[t] = o;
+    } else {
+      row[t] = 0.f;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace caiman
+
+extern "C" int caiman_logmel_forward(const float* audio, const int32_t* audio_len, int64_t B, int64_t max_samples,
+                                     int win_len, int hop, int nfft, int nmel, int initial_pad, float preemph,
+                                     float dither, uint64_t seed, float log_floor, const float* window,
+                                     const float* tw_cos, const float* tw_sin, const float* mel_w,
+                                     const int32_t* mel_lo, const int32_t* mel_hi, float* out, int32_t* out_len,
+                                     int64_t max_frames, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(B >= 1 && B <= 65535 && max_samples >= 1 && max_frames >= 1, "logmel_forward: bad extents");
+  CAIMAN_CHECK(win_len >= 1 && hop >= 1 && win_len <= nfft && nmel >= 1, "logmel_forward: bad window / hop / nfft");
+  CAIMAN_CHECK(nfft == 256 || nfft == 512 || nfft == 1024, "logmel_forward: nfft must be 256, 512 or 1024 (got %d)", nfft);
+  CAIMAN_CHECK(audio && audio_len && window && tw_cos && tw_sin && mel_w && mel_lo && mel_hi && out && out_len,
+               "logmel_forward: null pointer");
+  int lg = 0;
+  while ((1 << lg) < nfft) ++lg;
+  MelParams p{audio, audio_len, window, tw_cos, tw_sin, mel_w, mel_lo, mel_hi, B, max_samples, max_frames,
+              win_len, hop, nfft, lg, nmel, initial_pad, preemph, dither, log_floor, seed};
+  const dim3 grid((unsigned)((max_frames + kFramesPerBlock - 1) / kFramesPerBlock), (unsigned)B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nfft == 256) hipLaunchKernelGGL((logmel_kernel<256>), grid, dim3(kFramesPerBlock * kWave), 0, st, p, out, out_len);
+  else if (nfft == 512) hipLaunchKernelGGL((logmel_kernel<512>), grid, dim3(kFramesPerBlock * kWave), 0, st, p, out, out_len);
+  else hipLaunchKernelGGL((logmel_kernel<1024>), grid, dim3(kFramesPerBlock * kWave), 0, st, p, out, out_len);
+  return check_launch("caiman_logmel_forward");
+}
+
+extern "C" int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int nmel, int64_t T, const float* ds_mean,
+                                    const float* ds_std, float ratio, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(B >= 1 && B <= 65535 && nmel >= 1 && T >= 1, "mel_normalize: bad extents");
+  CAIMAN_CHECK(x && len, "mel_normalize: null pointer");
+  CAIMAN_CHECK(ratio >= 0.f && ratio <= 1.f, "mel_normalize: ratio must be in [0,1]");
+  CAIMAN_CHECK(ratio == 0.f || (ds_mean && ds_std), "mel_normalize: dataset statistics required when ratio > 0");
+  hipLaunchKernelGGL(mel_normalize_kernel, dim3((unsigned)nmel, (unsigned)B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, len, T, nmel, ds_mean, ds_std, ratio);
+  return check_launch("caiman_mel_normalize");
+}

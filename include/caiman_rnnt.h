@@ -180,6 +180,35 @@ int caiman_lamb_step(float* p, float* g, float* m, float* v, float* ema,
                      int grad_averaging, int zero_grad, float* work, int32_t* step_counter,
                      caiman_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Log-mel frontend — replaces the DALI operator chain of the reference (third party, not
+ * vendored): construction training/caiman_asr_train/data/dali/pipeline.py:260-315, graph tail
+ * :439-462; base config training/configs/base-8703sp.yaml:37-49.
+ *   [0]*initial_pad ++ samples -> + dither*N(0,1) -> y[n] = x[n] - preemph*x[n-1] (clamped border)
+ *   -> frames of win_len every hop (no centring) x window -> zero-pad to nfft -> |FFT|^2
+ *   -> nmel triangular filters -> ln(max(., log_floor)) ; frames past the utterance are 0.
+ * audio : [B, max_samples] f32, audio_len : [B]; out : [B, nmel, max_frames] f32,
+ * out_len[b] = (audio_len[b] + initial_pad - win_len) / hop + 1.
+ * window [win_len], tw_cos/tw_sin [nfft/2] (cos / sin of 2*pi*k/nfft), mel_w [nmel, nfft/2+1]
+ * dense weights with [mel_lo, mel_hi) the non-zero bin range of each filter: DEVICE tables
+ * built once by the caller (caiman_asr_amd/data/frontend.py).
+ * ------------------------------------------------------------------------- */
+int caiman_logmel_forward(const float* audio, const int32_t* audio_len, int64_t B,
+                          int64_t max_samples, int win_len, int hop, int nfft, int nmel,
+                          int initial_pad, float preemph, float dither, uint64_t seed,
+                          float log_floor, const float* window, const float* tw_cos,
+                          const float* tw_sin, const float* mel_w, const int32_t* mel_lo,
+                          const int32_t* mel_hi, float* out, int32_t* out_len,
+                          int64_t max_frames, caiman_stream_t stream);
+
+/* In-place per-feature normalisation over the valid frames, blended with dataset statistics:
+ *   ratio*(x - ds_mean)/ds_std + (1 - ratio)*(x - mean_utt)/std_utt   (population std),
+ * training/caiman_asr_train/data/dali/mel_normalization.py:85-118.  ds_* may be NULL when
+ * ratio == 0.  Frames >= len[b] are zeroed. */
+int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int nmel, int64_t T,
+                         const float* ds_mean, const float* ds_std, float ratio,
+                         caiman_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,30 @@ def test_model_refuses_cpu_tensors_and_cpu_fallbacks():
         RNNT(n_classes=30, **dict(cfg, gpu_unavailable=True))
     with pytest.raises(ValueError, match="quantize"):
         RNNT(n_classes=30, **dict(cfg, quantize=True))
+
+
+def test_norm_blend_ratio_schedule():
+    # training/caiman_asr_train/data/dali/mel_normalization.py:85-101
+    from caiman_asr_amd.data.frontend import MelFeatNormalizer, NormType, norm_ramp_params
+
+    m, s = torch.zeros(80), torch.ones(80)
+    nz = MelFeatNormalizer(m, s, 100, 200, 0.25, NormType.BLENDED_STATS)
+    assert [nz._calc_ratio(k) for k in (0, 100, 150, 200, 999)] == [0.25, 0.25, 0.625, 1.0, 1.0]
+    assert MelFeatNormalizer(m, s, None, None, 0.25, NormType.DATASET_STATS)._calc_ratio(5) == 1.0
+    assert MelFeatNormalizer(None, None, None, None, 0.25, NormType.UTTERANCE_STATS)._calc_ratio(5) == 0.0
+    assert norm_ramp_params(NormType.BLENDED_STATS, 1632, 18000, 10880) == (30512, 35512)
+    assert norm_ramp_params(NormType.DATASET_STATS, 1, 2, 3) == (None, None)
+
+
+def test_mel_filterbank_tables():
+    from caiman_asr_amd.data.frontend import hann_window, mel_filterbank
+    from oracle import frontend as of
+
+    w = mel_filterbank(16000, 512, 80)
+    assert w.shape == (80, 257) and (w >= 0).all()
+    # two independent constructions (vectorised product table vs per-bin oracle loops) agree
+    assert np.allclose(w, of.mel_weights(16000, 512, 80), atol=1e-12)
+    # Slaney area normalisation: each triangle integrates to ~1 over Hz
+    area = w.sum(1) * (16000 / 512)
+    assert np.allclose(area[5:], 1.0, atol=0.12)
+    assert np.allclose(hann_window(400), of._hann_dali(400))
