@@ -181,6 +181,22 @@ def main():
         rows.append([step] + [g["lr"] for g in o.param_groups])
     json.dump(dict(initial_lr=init, min_lr=4e-4, warmup=1632, hold=18000, half_life=10880, rows=rows),
               open(os.path.join(OUT, "lr_policy.json"), "w"))
+    # ---- 4. frontend: the reference's own golden log-mel tensor + the decoded test recording ------
+    # training/tests/data/dali/test_data_loader.py:235-258 compares the DALI val pipeline (testing config:
+    # window 0.02 s, no initial padding, per-utterance normalisation) on 2 copies of one 8.89 s FLAC with
+    # tests/test_data/audio_tensor_batch.pt (atol 2e-4).  Both rows of that tensor are identical; row 0 and
+    # the PCM samples (decoded with oracle/flac.py, no audio library in this image) are stored as data.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import flac
+
+    td = f"{REF}/tests/test_data"
+    pcm, sr, bps = flac.decode(f"{td}/gov_DOT_uscourts_DOT_ca9_DOT_04-56618_DOT_2006-02-16_DOT_mp3_00027.flac")
+    gold = torch.load(f"{td}/audio_tensor_batch.pt").numpy()
+    assert sr == 16000 and bps == 16 and pcm.shape[1] == 1 and np.array_equal(gold[0], gold[1])
+    np.savez_compressed(os.path.join(OUT, "frontend_ref.npz"), pcm=pcm[:, 0].astype(np.int16), sample_rate=sr,
+                        logmel_norm=gold[0].astype(np.float32), window_size=0.02, window_stride=0.01, n_fft=512)
+    for name in ("melmeans", "melvars"):
+        np.save(os.path.join(OUT, f"{name}.npy"), torch.load(f"{td}/{name}.pt").numpy())
     print("golden vectors written to", OUT)
 
 

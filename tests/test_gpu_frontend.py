@@ -78,3 +78,20 @@ def test_normalisation_matches_oracle(ratio):
     if ratio == 0.0:  # recoverable by hand: mean 0 / std 1 over valid frames (test_data_loader.py:334-383)
         v = out[1, :, :123]
         assert np.allclose(v.mean(1), 0, atol=1e-5) and np.allclose(v.std(1), 1, atol=1e-4)
+
+
+def test_hip_frontend_reproduces_the_reference_golden_logmel():
+    """HIP log-mel + utterance normalisation on the reference's test recording vs the reference's golden
+    tensor (tests/golden/frontend_ref.npz <- training/tests/test_data/audio_tensor_batch.pt, atol 2e-4 there)."""
+    import os
+
+    from caiman_asr_amd.data.frontend import LogMelFrontend, MelFeatNormalizer, NormType
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_ref.npz"))
+    x = torch.tensor(g["pcm"].astype(np.float32) / 32768.0, device=DEV).unsqueeze(0)
+    fe = LogMelFrontend(window_size=0.02, dither=0.0, turn_off_initial_padding=True, device=DEV)
+    out, n = fe(x, torch.tensor([x.shape[1]]))
+    assert int(n[0]) == 888
+    out = MelFeatNormalizer(None, None, None, None, 0.0, NormType.UTTERANCE_STATS)(out, n)
+    err = (out[0].cpu().numpy() - g["logmel_norm"])
+    assert np.abs(err).max() < 4e-4 and np.abs(err).mean() < 1e-5

@@ -213,3 +213,22 @@ def test_lstm_hard_gradients_by_finite_differences(T, B, H):
         num[i] = (f(gp) - f(gm)) / (2 * eps)
     # dG is the gradient w.r.t. the PRE-activation gates
     assert np.allclose(dG, num, atol=1e-5)
+
+
+def test_frontend_oracle_reproduces_the_reference_golden_logmel():
+    """The reference pins its DALI frontend with tests/test_data/audio_tensor_batch.pt at atol 2e-4
+    (training/tests/data/dali/test_data_loader.py:235-258).  The numpy oracle reproduces that tensor from
+    the decoded recording: mean |err| ~1.6e-6, max 2.2e-4 (the reference tensor was produced in float32 with
+    1e-5 dither, hence the slightly wider bound on the max)."""
+    import os
+
+    from oracle import frontend as of
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_ref.npz"))
+    x = g["pcm"].astype(np.float64) / 32768.0
+    lm = of.logmel(x, win=int(g["window_size"] * 16000), hop=160, nfft=512, nmel=80, initial_pad=0)
+    assert lm.shape == g["logmel_norm"].shape == (80, 888)
+    nm = of.normalize(lm, lm.shape[1])
+    err = np.abs(nm - g["logmel_norm"])
+    assert err.max() < 3e-4 and err.mean() < 5e-6
+    assert (err > 2e-4).sum() <= 3
