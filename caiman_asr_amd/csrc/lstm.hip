@@ -18,6 +18,8 @@
 //   element is used once per workgroup, so LDS staging would be pure overhead — guide §5
 //   "GEMV / M<=16" row); see the MFMA section below for the layout and the measurements.
 // A generic scalar kernel covers f32 / f64 and sizes the MFMA tiles do not divide.
+#include <algorithm>
+
 #include "common.h"
 
 namespace caiman {
@@ -192,16 +194,57 @@ __device__ __forceinline__ int64_t tiled_index(int b, int k, int nk) {
   return (((int64_t)(b >> 5) * nk + (k >> 5)) * 32 + (b & 31)) * 32 + (k & 31);
 }
 
-// ---- forward step: grid (H/4, ceil(B/32)), 256 threads = 4 waves --------------------------
+// A launch ("wave") can advance SEVERAL independent recurrences at once: blockIdx.z selects a slot
+// (one LSTM layer working on its own timestep).  That is how a stack of layers is pipelined: layer l
+// runs a chunk of timesteps behind layer l-1, so the number of dependent kernel boundaries is
+// T + (L-1)*chunk instead of L*T while every launch carries L times the work.
+constexpr int kMaxSlots = 8;
+
+template <typename T>
+struct FwdSlots {
+  const T* Rtile[kMaxSlots];
+  T* g[kMaxSlots];      // gates of the slot's first step (rows advance by B*4H per launch)
+  T* c[kMaxSlots];      // c row of the slot's first step INPUT; output row = +B*H
+  T* y[kMaxSlots];      // y row matching c (row-major output goes to the next row)
+  T* hring[kMaxSlots];  // 2 x pad32(B) x H tiled
+  int parity[kMaxSlots];  // ring half that holds h of the slot's first step input
+  int nsteps[kMaxSlots];
+};
+
+template <typename T>
+struct BwdSlots {
+  const T* Rttile[kMaxSlots];
+  const T* g[kMaxSlots];      // activated gates of the slot's LAST timestep t_hi (rows go down per launch)
+  const T* c[kMaxSlots];      // c row t_hi (c_prev); c_cur = +B*H
+  const T* delta[kMaxSlots];  // upstream gradient row t_hi
+  int64_t d_st[kMaxSlots], d_sb[kMaxSlots];
+  T* dG[kMaxSlots];           // dG row t_hi
+  T* dring[kMaxSlots];        // 2 x pad32(B) x 4H tiled
+  float* dC[kMaxSlots];
+  int parity[kMaxSlots];      // t_hi & 1
+  int nsteps[kMaxSlots];
+  int has_in0[kMaxSlots];     // 0 when t_hi is the last timestep of the sequence (no dG[t+1])
+};
+
+// ---- forward step: grid (H/4, ceil(B/32), slots), 256 threads = 4 waves -----------------------
 //   output tile: 32 batch rows x 16 gate columns (4 gates x 4 hidden units); the H/32 k-steps
 //   are dealt round-robin to the 4 waves; NK = k-steps per wave (0 = runtime loop).
 template <typename T, bool HARD, int NK>
-__global__ __launch_bounds__(256) void lstm_fwd_step_mfma(const T* __restrict__ Rtile, T* __restrict__ g,
-                                                          const T* __restrict__ c0, T* __restrict__ c1,
-                                                          const T* __restrict__ h_in, T* __restrict__ y1,
-                                                          T* __restrict__ h_out, int B, int H) {
+__global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int step, int B, int H) {
   using frag = typename frag8<T>::type;
   __shared__ float tile[4][2][16][17];
+  const int slot = blockIdx.z;
+  if (step >= w.nsteps[slot]) return;
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+  const T* __restrict__ Rtile = w.Rtile[slot];
+  T* __restrict__ g = w.g[slot] + go * step;
+  const T* __restrict__ c0 = w.c[slot] + so * step;
+  T* __restrict__ c1 = w.c[slot] + so * (step + 1);
+  T* __restrict__ y1 = w.y[slot] + so * (step + 1);
+  const T* __restrict__ h_in = w.hring[slot] + ((w.parity[slot] + step) & 1) * hsz;
+  T* __restrict__ h_out = w.hring[slot] + ((w.parity[slot] + step + 1) & 1) * hsz;
+
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int j0 = blockIdx.x * 4, mt = blockIdx.y, m0 = mt * 32;
@@ -243,7 +286,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(const T* __restrict__ 
       acc1 = mfma16(a1[i], bf[i], acc1);
     }
   } else {
-#pragma unroll 4
     for (int s = wave; s < nk; s += 4) {
       const frag bb = *reinterpret_cast<const frag*>(Bbase + (int64_t)s * 512);
       const frag a0 = *reinterpret_cast<const frag*>(Abase + (int64_t)s * 1024);
@@ -279,18 +321,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(const T* __restrict__ 
   g[gb + 3 * (int64_t)H] = static_cast<T>(o);
 }
 
-// ---- backward step: grid (H/16, ceil(B/32)), 1024 threads = 16 waves ------------------------
+// ---- backward step: grid (H/16, ceil(B/32), slots), 1024 threads = 16 waves ---------------------
 //   dh tile: 32 batch rows x 16 hidden units, K = 4H dealt round-robin to the 16 waves.
 template <typename T, bool HARD, int NK>
-__global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(const T* __restrict__ Rttile, const T* __restrict__ g,
-                                                           const T* __restrict__ c_prev,
-                                                           const T* __restrict__ c_cur,
-                                                           const T* __restrict__ delta, int64_t d_sb,
-                                                           const T* __restrict__ dG_in, T* __restrict__ dG,
-                                                           T* __restrict__ dG_out, float* __restrict__ dC, int B,
-                                                           int H) {
+__global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int step, int B, int H) {
   using frag = typename frag8<T>::type;
   __shared__ float tile[16][2][16][17];
+  const int slot = blockIdx.z;
+  if (step >= w.nsteps[slot]) return;
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+  const T* __restrict__ Rttile = w.Rttile[slot];
+  const T* __restrict__ g = w.g[slot] - go * step;
+  const T* __restrict__ c_prev = w.c[slot] - so * step;
+  const T* __restrict__ c_cur = c_prev + so;
+  const T* __restrict__ delta = w.delta[slot] - w.d_st[slot] * step;
+  const int64_t d_sb = w.d_sb[slot];
+  T* __restrict__ dG = w.dG[slot] - go * step;
+  const bool has_in = step > 0 || w.has_in0[slot];
+  const T* __restrict__ dG_in = w.dring[slot] + ((w.parity[slot] + step + 1) & 1) * dsz;
+  T* __restrict__ dG_out = w.dring[slot] + ((w.parity[slot] + step) & 1) * dsz;
+  float* __restrict__ dC = w.dC[slot];
+
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = blockIdx.x * 16, mt = blockIdx.y, m0 = mt * 32;
   const int nk4 = (4 * H) >> 5;
@@ -299,19 +351,19 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(const T* __restrict__
   const int be = m0 + eb, ne = n0 + eu;
   const bool ep = (tid < 512) && (be < B);
   const int64_t gb = (int64_t)be * 4 * H + ne;
-  float dy = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cp = 0.f, cc = 0.f, dcf = 0.f;
+  float dy = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go_ = 0.f, cp = 0.f, cc = 0.f, dcf = 0.f;
   if (ep) {
     dy = static_cast<float>(delta[(int64_t)be * d_sb + ne]);
     gi = static_cast<float>(g[gb]);
     gf = static_cast<float>(g[gb + H]);
     gg = static_cast<float>(g[gb + 2 * (int64_t)H]);
-    go = static_cast<float>(g[gb + 3 * (int64_t)H]);
+    go_ = static_cast<float>(g[gb + 3 * (int64_t)H]);
     cp = static_cast<float>(c_prev[(int64_t)be * H + ne]);
     cc = static_cast<float>(c_cur[(int64_t)be * H + ne]);
     dcf = dC[(int64_t)be * H + ne];
   }
 
-  if (dG_in) {
+  if (has_in) {
     const int r = lane & 15, kq = lane >> 4;
     const T* Bbase = Rttile + ((int64_t)blockIdx.x * nk4 * 16 + r) * 32 + 8 * kq;  // + s*512
     const T* Abase = dG_in + ((int64_t)mt * nk4 * 32 + r) * 32 + 8 * kq;           // + s*1024 (+512)
@@ -336,7 +388,6 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(const T* __restrict__
         acc1 = mfma16(a1[i], bf[i], acc1);
       }
     } else {
-#pragma unroll 2
       for (int s = wave; s < nk4; s += 16) {
         const frag bb = *reinterpret_cast<const frag*>(Bbase + (int64_t)s * 512);
         const frag a0 = *reinterpret_cast<const frag*>(Abase + (int64_t)s * 1024);
@@ -353,23 +404,22 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(const T* __restrict__
   }
   __syncthreads();
   if (!ep) return;
-  if (dG_in) {
+  if (has_in) {
     const int half = eb >> 4, rr = eb & 15;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) dy += tile[w][half][rr][eu];
+    for (int q = 0; q < 16; ++q) dy += tile[q][half][rr][eu];
   }
   const float ct = Act<float, HARD>::tanhv(cc);
-  const float dc = dy * go * Act<float, HARD>::tanh_prime(ct) + dcf;
+  const float dc = dy * go_ * Act<float, HARD>::tanh_prime(ct) + dcf;
   const T vI = static_cast<T>(dc * gg * Act<float, HARD>::sigm_prime(gi));
   const T vF = static_cast<T>(dc * cp * Act<float, HARD>::sigm_prime(gf));
   const T vG = static_cast<T>(dc * gi * Act<float, HARD>::tanh_prime(gg));
-  const T vO = static_cast<T>(dy * ct * Act<float, HARD>::sigm_prime(go));
-  if (dG_out) {  // tiled copy for the next (earlier-in-time) step
-    dG_out[tiled_index(be, ne, nk4)] = vI;
-    dG_out[tiled_index(be, H + ne, nk4)] = vF;
-    dG_out[tiled_index(be, 2 * H + ne, nk4)] = vG;
-    dG_out[tiled_index(be, 3 * H + ne, nk4)] = vO;
-  }
+  const T vO = static_cast<T>(dy * ct * Act<float, HARD>::sigm_prime(go_));
+  // tiled copy for the next (earlier-in-time) step
+  dG_out[tiled_index(be, ne, nk4)] = vI;
+  dG_out[tiled_index(be, H + ne, nk4)] = vF;
+  dG_out[tiled_index(be, 2 * H + ne, nk4)] = vG;
+  dG_out[tiled_index(be, 3 * H + ne, nk4)] = vO;
   dG[gb] = vI;
   dG[gb + H] = vF;
   dG[gb + 2 * (int64_t)H] = vG;
@@ -383,38 +433,78 @@ constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_
 inline int64_t pad32(int64_t b) { return (b + 31) / 32 * 32; }
 
 template <typename T, bool HARD>
+int launch_fwd_waves(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s) {
+  const int nkw = (int)(((H >> 5) + 3) / 4);  // k-steps per wave
+  const dim3 grid((unsigned)(H / 4), (unsigned)((B + 31) / 32), (unsigned)n_slots);
+  for (int i = 0; i < n_launches; ++i) {
+#define CAIMAN_FWD(NKV) hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD, NKV>), grid, dim3(256), 0, s, w, i, (int)B, (int)H)
+    switch (nkw) {
+      case 1: CAIMAN_FWD(1); break;
+      case 2: CAIMAN_FWD(2); break;
+      case 4: CAIMAN_FWD(4); break;
+      case 6: CAIMAN_FWD(6); break;
+      case 8: CAIMAN_FWD(8); break;
+      case 12: CAIMAN_FWD(12); break;
+      default: CAIMAN_FWD(0); break;
+    }
+#undef CAIMAN_FWD
+  }
+  return check_launch("lstm forward wave");
+}
+
+template <typename T, bool HARD>
+int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s) {
+  const int nkw = (int)(((4 * H >> 5) + 15) / 16);
+  const dim3 grid((unsigned)(H / 16), (unsigned)((B + 31) / 32), (unsigned)n_slots);
+  for (int i = 0; i < n_launches; ++i) {
+#define CAIMAN_BWD(NKV) hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD, NKV>), grid, dim3(1024), 0, s, w, i, (int)B, (int)H)
+    switch (nkw) {
+      case 1: CAIMAN_BWD(1); break;
+      case 2: CAIMAN_BWD(2); break;
+      case 4: CAIMAN_BWD(4); break;
+      case 6: CAIMAN_BWD(6); break;
+      case 8: CAIMAN_BWD(8); break;
+      default: CAIMAN_BWD(0); break;
+    }
+#undef CAIMAN_BWD
+  }
+  return check_launch("lstm backward wave");
+}
+
+template <typename T>
+int prepare_fwd(const T* R, const T* h0, T* Rtile, T* hring, int64_t B, int64_t H, hipStream_t s) {
+  if (hipMemsetAsync(hring, 0, sizeof(T) * (size_t)(2 * pad32(B) * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+  hipLaunchKernelGGL((tile_R_fwd_kernel<T>), dim3((unsigned)((4 * H * H + 255) / 256)), dim3(256), 0, s, R, Rtile, (int)H);
+  hipLaunchKernelGGL((tile_rows_kernel<T>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, h0, hring, (int)B, (int)H);
+  return check_launch("lstm prepare forward");
+}
+
+template <typename T>
+int prepare_bwd(const T* R, T* Rttile, T* dring, float* dC, int64_t B, int64_t H, hipStream_t s) {
+  if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * pad32(B) * 4 * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+  if (hipMemsetAsync(dC, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+  hipLaunchKernelGGL((tile_Rt_bwd_kernel<T>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
+  return check_launch("lstm prepare backward");
+}
+
+template <typename T, bool HARD>
 int run_fwd(const T* R, T* gates, T* c, T* y, T* work, int64_t Tn, int64_t B, int64_t H, hipStream_t s) {
   const int64_t go = B * 4 * H, so = B * H;
-  bool mfma = false;
-  if constexpr (kHasMfma<T>) mfma = (H % 32 == 0) && work != nullptr;
   if constexpr (kHasMfma<T>) {
-    if (mfma) {
+    if ((H % 32 == 0) && work != nullptr) {
       T* Rtile = work;
       T* hring = work + 4 * H * H;
-      const int64_t hsz = pad32(B) * H;
-      if (hipMemsetAsync(hring, 0, sizeof(T) * (size_t)(2 * hsz), s) != hipSuccess) return check_launch("lstm_fwd memset");
-      hipLaunchKernelGGL((tile_R_fwd_kernel<T>), dim3((unsigned)((4 * H * H + 255) / 256)), dim3(256), 0, s, R, Rtile, (int)H);
-      hipLaunchKernelGGL((tile_rows_kernel<T>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, y, hring, (int)B, (int)H);
-      const int nkw = (int)(((H >> 5) + 3) / 4);  // k-steps per wave
-      const dim3 grid((unsigned)(H / 4), (unsigned)((B + 31) / 32));
-      for (int64_t t = 0; t < Tn; ++t) {
-        T* hin = hring + (t & 1) * hsz;
-        T* hout = hring + ((t + 1) & 1) * hsz;
-#define CAIMAN_FWD(NKV)                                                                                       \
-  hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD, NKV>), grid, dim3(256), 0, s, Rtile, gates + go * t,        \
-                     c + so * t, c + so * (t + 1), hin, y + so * (t + 1), hout, (int)B, (int)H)
-        switch (nkw) {
-          case 1: CAIMAN_FWD(1); break;
-          case 2: CAIMAN_FWD(2); break;
-          case 4: CAIMAN_FWD(4); break;
-          case 6: CAIMAN_FWD(6); break;
-          case 8: CAIMAN_FWD(8); break;
-          case 12: CAIMAN_FWD(12); break;
-          default: CAIMAN_FWD(0); break;
-        }
-#undef CAIMAN_FWD
+      if (int e = prepare_fwd<T>(R, y, Rtile, hring, B, H, s)) return e;
+      FwdSlots<T> w{};
+      w.Rtile[0] = Rtile; w.g[0] = gates; w.c[0] = c; w.y[0] = y; w.hring[0] = hring; w.parity[0] = 0;
+      // the launch index is an int: feed the sequence in pieces so `nsteps` stays small
+      for (int64_t t0 = 0; t0 < Tn; t0 += 4096) {
+        const int n = (int)std::min<int64_t>(4096, Tn - t0);
+        w.g[0] = gates + go * t0; w.c[0] = c + so * t0; w.y[0] = y + so * t0;
+        w.parity[0] = (int)(t0 & 1); w.nsteps[0] = n;
+        if (int e = launch_fwd_waves<T, HARD>(w, 1, n, B, H, s)) return e;
       }
-      return check_launch("caiman_lstm_fused_fwd");
+      return CAIMAN_OK;
     }
   }
   for (int64_t t = 0; t < Tn; ++t)
@@ -428,39 +518,23 @@ template <typename T, bool HARD>
 int run_bwd(const T* R, const T* gates, const T* c, const T* delta, int64_t d_st, int64_t d_sb, T* dG,
             acc_t<T>* dC, T* work, int64_t Tn, int64_t B, int64_t H, hipStream_t s) {
   const int64_t go = B * 4 * H, so = B * H;
-  if (hipMemsetAsync(dC, 0, sizeof(acc_t<T>) * (size_t)so, s) != hipSuccess) return check_launch("lstm_bwd memset");
-  bool mfma = false;
-  if constexpr (kHasMfma<T>) mfma = (H % 32 == 0) && work != nullptr;
   if constexpr (kHasMfma<T>) {
-    if (mfma) {
+    if ((H % 32 == 0) && work != nullptr) {
       T* Rttile = work;
       T* dring = work + 4 * H * H;
-      const int64_t dsz = pad32(B) * 4 * H;
-      if (Tn > 1) {
-        if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * dsz), s) != hipSuccess) return check_launch("lstm_bwd memset");
-        hipLaunchKernelGGL((tile_Rt_bwd_kernel<T>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
+      if (int e = prepare_bwd<T>(R, Rttile, dring, dC, B, H, s)) return e;
+      BwdSlots<T> w{};
+      w.Rttile[0] = Rttile; w.dring[0] = dring; w.dC[0] = dC; w.d_st[0] = d_st; w.d_sb[0] = d_sb;
+      for (int64_t thi = Tn - 1; thi >= 0; thi -= 4096) {
+        const int n = (int)std::min<int64_t>(4096, thi + 1);
+        w.g[0] = gates + go * thi; w.c[0] = c + so * thi; w.delta[0] = delta + d_st * thi; w.dG[0] = dG + go * thi;
+        w.parity[0] = (int)(thi & 1); w.nsteps[0] = n; w.has_in0[0] = thi < Tn - 1;
+        if (int e = launch_bwd_waves<T, HARD>(w, 1, n, B, H, s)) return e;
       }
-      const int nkw = (int)(((4 * H >> 5) + 15) / 16);
-      const dim3 grid((unsigned)(H / 16), (unsigned)((B + 31) / 32));
-      for (int64_t t = Tn - 1; t >= 0; --t) {
-        const T* din = (t < Tn - 1) ? dring + ((t + 1) & 1) * dsz : nullptr;
-        T* dout = (t > 0) ? dring + (t & 1) * dsz : nullptr;
-#define CAIMAN_BWD(NKV)                                                                                       \
-  hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD, NKV>), grid, dim3(1024), 0, s, Rttile, gates + go * t,      \
-                     c + so * t, c + so * (t + 1), delta + d_st * t, d_sb, din, dG + go * t, dout, dC, (int)B, (int)H)
-        switch (nkw) {
-          case 1: CAIMAN_BWD(1); break;
-          case 2: CAIMAN_BWD(2); break;
-          case 4: CAIMAN_BWD(4); break;
-          case 6: CAIMAN_BWD(6); break;
-          case 8: CAIMAN_BWD(8); break;
-          default: CAIMAN_BWD(0); break;
-        }
-#undef CAIMAN_BWD
-      }
-      return check_launch("caiman_lstm_fused_bwd");
+      return CAIMAN_OK;
     }
   }
+  if (hipMemsetAsync(dC, 0, sizeof(acc_t<T>) * (size_t)so, s) != hipSuccess) return check_launch("lstm_bwd memset");
   for (int64_t t = Tn - 1; t >= 0; --t) {
     const T* dgn = (t < Tn - 1) ? dG + go * (t + 1) : nullptr;
     hipLaunchKernelGGL((lstm_bwd_step_generic<T, HARD>), dim3((unsigned)((H + 63) / 64), (unsigned)B), dim3(64),
@@ -477,6 +551,74 @@ extern "C" int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backwar
   if (B < 1 || H < 1) return 0;
   const int64_t bp = (B + 31) / 32 * 32;
   return 4 * H * H + 2 * bp * (backward ? 4 * H : H);
+}
+
+// ---- multi-layer ("wave") interface -----------------------------------------------------------------
+extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
+                                   int64_t B, int64_t H, int dtype, int backward, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(B >= 1 && H >= 32 && H % 32 == 0, "lstm_prepare: H must be a positive multiple of 32 (got %lld)", (long long)H);
+  CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "lstm_prepare: the wave interface is f16 / bf16 only");
+  CAIMAN_CHECK(R && weights_tiled && ring && (backward ? dC != nullptr : h0 != nullptr), "lstm_prepare: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == CAIMAN_BF16)
+    return backward ? prepare_bwd<bf16_t>((const bf16_t*)R, (bf16_t*)weights_tiled, (bf16_t*)ring, (float*)dC, B, H, s)
+                    : prepare_fwd<bf16_t>((const bf16_t*)R, (const bf16_t*)h0, (bf16_t*)weights_tiled, (bf16_t*)ring, B, H, s);
+  return backward ? prepare_bwd<f16_t>((const f16_t*)R, (f16_t*)weights_tiled, (f16_t*)ring, (float*)dC, B, H, s)
+                  : prepare_fwd<f16_t>((const f16_t*)R, (const f16_t*)h0, (f16_t*)weights_tiled, (f16_t*)ring, B, H, s);
+}
+
+extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches, int64_t B,
+                                    int64_t H, int dtype, int hard, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(slots && n_slots >= 1 && n_slots <= kMaxSlots, "lstm_wave_fwd: 1..%d slots", kMaxSlots);
+  CAIMAN_CHECK(B >= 1 && B <= 32 * 65535 && H >= 32 && H % 32 == 0, "lstm_wave_fwd: bad extents");
+  CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "lstm_wave_fwd: f16 / bf16 only");
+  CAIMAN_CHECK(n_launches >= 0, "lstm_wave_fwd: negative launch count");
+  if (n_launches == 0) return CAIMAN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto go_ = [&](auto tag) -> int {
+    using T = decltype(tag);
+    FwdSlots<T> w{};
+    for (int i = 0; i < n_slots; ++i) {
+      CAIMAN_CHECK(slots[i].weights_tiled && slots[i].gates && slots[i].c && slots[i].y && slots[i].ring,
+                   "lstm_wave_fwd: null pointer in slot %d", i);
+      CAIMAN_CHECK(slots[i].nsteps >= 0 && slots[i].nsteps <= n_launches, "lstm_wave_fwd: slot %d nsteps out of range", i);
+      w.Rtile[i] = (const T*)slots[i].weights_tiled; w.g[i] = (T*)slots[i].gates; w.c[i] = (T*)slots[i].c;
+      w.y[i] = (T*)slots[i].y; w.hring[i] = (T*)slots[i].ring; w.parity[i] = slots[i].parity & 1;
+      w.nsteps[i] = slots[i].nsteps;
+    }
+    return hard ? launch_fwd_waves<T, true>(w, n_slots, n_launches, B, H, s)
+                : launch_fwd_waves<T, false>(w, n_slots, n_launches, B, H, s);
+  };
+  return dtype == CAIMAN_BF16 ? go_(bf16_t{}) : go_(f16_t{});
+}
+
+extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n_launches, int64_t B,
+                                    int64_t H, int dtype, int hard, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(slots && n_slots >= 1 && n_slots <= kMaxSlots, "lstm_wave_bwd: 1..%d slots", kMaxSlots);
+  CAIMAN_CHECK(B >= 1 && B <= 32 * 65535 && H >= 32 && H % 32 == 0, "lstm_wave_bwd: bad extents");
+  CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "lstm_wave_bwd: f16 / bf16 only");
+  CAIMAN_CHECK(n_launches >= 0, "lstm_wave_bwd: negative launch count");
+  if (n_launches == 0) return CAIMAN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto go_ = [&](auto tag) -> int {
+    using T = decltype(tag);
+    BwdSlots<T> w{};
+    for (int i = 0; i < n_slots; ++i) {
+      CAIMAN_CHECK(slots[i].weights_tiled && slots[i].gates && slots[i].c && slots[i].delta && slots[i].dG &&
+                       slots[i].ring && slots[i].dC, "lstm_wave_bwd: null pointer in slot %d", i);
+      CAIMAN_CHECK(slots[i].nsteps >= 0 && slots[i].nsteps <= n_launches, "lstm_wave_bwd: slot %d nsteps out of range", i);
+      w.Rttile[i] = (const T*)slots[i].weights_tiled; w.g[i] = (const T*)slots[i].gates; w.c[i] = (const T*)slots[i].c;
+      w.delta[i] = (const T*)slots[i].delta; w.d_st[i] = slots[i].delta_stride_t; w.d_sb[i] = slots[i].delta_stride_b;
+      w.dG[i] = (T*)slots[i].dG; w.dring[i] = (T*)slots[i].ring; w.dC[i] = (float*)slots[i].dC;
+      w.parity[i] = slots[i].parity & 1; w.nsteps[i] = slots[i].nsteps; w.has_in0[i] = slots[i].has_next ? 1 : 0;
+    }
+    return hard ? launch_bwd_waves<T, true>(w, n_slots, n_launches, B, H, s)
+                : launch_bwd_waves<T, false>(w, n_slots, n_launches, B, H, s);
+  };
+  return dtype == CAIMAN_BF16 ? go_(bf16_t{}) : go_(f16_t{});
 }
 
 extern "C" int caiman_lstm_fused_fwd(const void* R, void* gates, void* c, void* y, void* work, int64_t T,

@@ -121,6 +121,7 @@ class CustomLSTM(torch.nn.Module):
         self.hard = hard
         self.rw_dropout = rw_dropout
         self.drop_function = torch.nn.Dropout(p=dropout) if dropout != 0.0 else torch.nn.Identity()
+        self.pipeline_layers = True  # layer-pipelined schedule for f16/bf16 stacks (custom_lstm/stack.py)
         kw = dict(hidden_size=hidden_size, hard=hard, rw_dropout=rw_dropout, dtype=dtype, device=device)
         self.layers = [Layer(input_size, **kw)]
         self.layers.extend(Layer(hidden_size, **kw) for _ in range(num_layers - 1))
@@ -149,6 +150,25 @@ class CustomLSTM(torch.nn.Module):
     def forward(self, input: Ten, state: Optional[Tuple[Ten, Ten]] = None
                 ) -> Tuple[Ten, Tuple[Ten, Ten], Tuple[Ten, Ten]]:
         """-> (output [T,B,H], (h_n, c_n) [L,B,H], (all_h, all_c) [L,T,B,H])."""
+        from caiman_asr_amd.rnnt_ext.custom_lstm import stack
+
+        gate_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else input.dtype
+        if self.pipeline_layers and self.rw_dropout == 0.0 and stack.eligible(input, self.hidden_size, self.num_layers,
+                                                                              gate_dtype):
+            # whole-stack layer pipeline (same kernels and GEMM operands, different schedule)
+            L = self.num_layers
+            if state is None:
+                h0 = torch.zeros((L, input.shape[1], self.hidden_size), device=input.device, dtype=input.dtype)
+                c0 = torch.zeros_like(h0)
+            else:
+                h0, c0 = state[0].detach(), state[1].detach()
+            params = []
+            for layer in self.layers:
+                params += [layer.weight_ih, layer.weight_hh, layer.bias_ih, layer.bias_hh]
+            y, all_h, all_c = stack.StackFunction.apply(input, h0, c0, self.hard, float(self.bl_dropout), self.training,
+                                                        *params)
+            return y, (all_h[:, -1], all_c[:, -1]), (all_h, all_c)
+
         h_fl, c_fl, all_h_fl, all_c_fl = [], [], [], []
         x = None
         for i, layer in enumerate(self.layers):

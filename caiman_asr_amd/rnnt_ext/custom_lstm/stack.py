@@ -1,0 +1,178 @@
+"""Layer-pipelined ("wavefront") execution of a whole LSTM stack on the gfx950 kernels.
+
+The reference runs the layers of a stack one after the other, each as T dependent launches
+(training/lib/src/rnnt_ext/custom_lstm/lstm.py:364-391 -> training/lib/csrc/lstm.cu:259-271), i.e. L*T
+kernel boundaries.  On MI355X a boundary costs ~1.5 us of GPU time and the step kernel is latency-bound, so
+the stack is restructured as a software pipeline over CHUNKS of timesteps:
+
+    tick tau:  layer l advances chunk (tau - l)   for every l with 0 <= tau - l < n_chunks
+
+All layers active in a tick are advanced by ONE launch per timestep (csrc/lstm.hip, blockIdx.z = layer),
+which needs T + (L-1)*chunk launches instead of L*T.  Between ticks the input GEMM of each layer's next
+chunk (x·Wᵀ + b on the chunk the layer below has just produced) is a plain library GEMM.  The backward
+pass is the mirror image (top layer first, time reversed); weight gradients are batched GEMMs at the end.
+
+Numerics are those of the per-layer path (same kernels, same GEMM operands); only the schedule differs.
+"""
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from caiman_asr_amd import _lib
+from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
+
+CHUNK = 32
+
+
+def eligible(x: torch.Tensor, hidden_size: int, num_layers: int, gate_dtype) -> bool:
+    return (x.is_cuda and num_layers >= 2 and num_layers <= 8 and hidden_size % 32 == 0
+            and gate_dtype in (torch.float16, torch.bfloat16))
+
+
+class _Scratch:
+    """Per-(device, stream) cache of tiled weights / rings so successive steps reuse the allocations."""
+    cache = {}
+
+    @classmethod
+    def get(cls, key, numel, dtype, device):
+        k = (key, device, dtype, torch.cuda.current_stream(device).cuda_stream)
+        t = cls.cache.get(k)
+        if t is None or t.numel() < numel:
+            t = torch.empty(numel, dtype=dtype, device=device)
+            cls.cache[k] = t
+        return t[:numel]
+
+
+def _pad32(b):
+    return (b + 31) // 32 * 32
+
+
+class StackFunction(torch.autograd.Function):
+    """forward(x [T,B,I], h0 [L,B,H], c0 [L,B,H], hard, p_drop, training, W_0, R_0, bW_0, bR_0, W_1, ...)
+    -> (y_top [T,B,H], all_h [L,T,B,H], all_c [L,T,B,H]).  Gradients flow to x and the parameters."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, h0, c0, hard, p_drop, training, *params):
+        L = len(params) // 4
+        Ws, Rs, bWs, bRs = params[0::4], params[1::4], params[2::4], params[3::4]
+        T, B, _ = x.shape
+        H = Rs[0].shape[1]
+        dev = x.device
+        lib = _lib.lib()
+        # layer 0: every timestep's input contribution in one GEMM (autocast decides the gate dtype)
+        g0 = torch.addmm(bWs[0] + bRs[0], x.flatten(0, 1), Ws[0].t())
+        dt = g0.dtype
+        tag = _lib.dtype_tag(dt)
+        G = torch.empty((L, T, B, 4 * H), dtype=dt, device=dev)
+        G[0].copy_(g0.view(T, B, 4 * H))
+        del g0
+        Y = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
+        Cs = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
+        Y[:, 0].copy_(h0)
+        Cs[:, 0].copy_(c0)
+        Rp = [R.to(dt).contiguous() for R in Rs]
+        Wp = [W.to(dt) for W in Ws]
+        bias = [(bWs[l] + bRs[l]).to(dt) for l in range(L)]
+        masks: List[Optional[torch.Tensor]] = [None] * L
+        if training and p_drop > 0.0:
+            for l in range(1, L):
+                masks[l] = (torch.rand((T, B, H), device=dev) >= p_drop).to(dt) * (1.0 / (1.0 - p_drop))
+        bp = _pad32(B)
+        wt = _Scratch.get("fw", L * 4 * H * H, dt, dev).view(L, -1)
+        ring = _Scratch.get("fr", L * 2 * bp * H, dt, dev).view(L, -1)
+        st = _lib.stream()
+        for l in range(L):
+            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]), _lib.ptr(ring[l]),
+                                                None, B, H, tag, 0, st))
+        n_ch = (T + CHUNK - 1) // CHUNK
+        es = G.element_size()
+        with _lib.timed("lstm_fwd", T * L, T * L * _step_bytes(B, H, es, False)):
+            for tau in range(n_ch + L - 1):
+                slots = []
+                for l in range(L):
+                    k = tau - l
+                    if k < 0 or k >= n_ch:
+                        continue
+                    t0, n = k * CHUNK, min(CHUNK, T - k * CHUNK)
+                    if l >= 1:  # input GEMM of this layer's chunk on what layer l-1 produced last tick
+                        xin = Y[l - 1, 1 + t0:1 + t0 + n]
+                        if masks[l] is not None:
+                            xin = xin * masks[l][t0:t0 + n]
+                        torch.addmm(bias[l], xin.reshape(n * B, H), Wp[l].t(), out=G[l, t0:t0 + n].view(n * B, 4 * H))
+                    slots.append(_lib.FwdSlot(wt[l].data_ptr(), G[l, t0].data_ptr(), Cs[l, t0].data_ptr(),
+                                              Y[l, t0].data_ptr(), ring[l].data_ptr(), t0 & 1, n))
+                arr = (_lib.FwdSlot * len(slots))(*slots)
+                _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots),
+                                                    max(s_.nsteps for s_ in slots), B, H, tag, int(hard), st))
+        ctx.save_for_backward(x, G, Y, Cs, *Wp, *Rp, *[m for m in masks if m is not None])
+        ctx.meta = (L, T, B, H, hard, [m is not None for m in masks], x.requires_grad)
+        y_top = Y[L - 1, 1:]
+        all_h, all_c = Y[:, 1:], Cs[:, 1:]
+        ctx.mark_non_differentiable(all_c)
+        return y_top, all_h, all_c
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, d_top, d_allh, _d_allc):
+        L, T, B, H, hard, has_mask, need_dx = ctx.meta
+        saved = ctx.saved_tensors
+        x, G, Y, Cs = saved[:4]
+        Wp, Rp = saved[4:4 + L], saved[4 + L:4 + 2 * L]
+        mask_list = list(saved[4 + 2 * L:])
+        masks = [mask_list.pop(0) if hm else None for hm in has_mask]
+        dev, dt = G.device, G.dtype
+        tag = _lib.dtype_tag(dt)
+        lib = _lib.lib()
+        st = _lib.stream()
+        dG = torch.empty_like(G)
+        # upstream gradient of every layer's output sequence; the top one arrives from autograd, the others
+        # are produced chunk by chunk from the layer above (plus any direct gradient on all_h)
+        delta = torch.zeros((L, T, B, H), dtype=dt, device=dev) if d_allh is None else d_allh.to(dt).clone()
+        if d_top is not None:
+            delta[L - 1] += d_top.to(dt)
+        bp = _pad32(B)
+        wt = _Scratch.get("bw", L * 4 * H * H, dt, dev).view(L, -1)
+        ring = _Scratch.get("br", L * 2 * bp * 4 * H, dt, dev).view(L, -1)
+        dC = _Scratch.get("bc", L * B * H, torch.float32, dev).view(L, -1)
+        for l in range(L):
+            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
+                                                B, H, tag, 1, st))
+        n_ch = (T + CHUNK - 1) // CHUNK
+        with _lib.timed("lstm_bwd", T * L, T * L * _step_bytes(B, H, G.element_size(), True)):
+            for tau in range(n_ch + L - 1):
+                slots = []
+                for l in range(L - 1, -1, -1):
+                    j = tau - (L - 1 - l)  # how many chunks this layer has already finished
+                    if j < 0 or j >= n_ch:
+                        continue
+                    k = n_ch - 1 - j
+                    t0, n = k * CHUNK, min(CHUNK, T - k * CHUNK)
+                    thi = t0 + n - 1
+                    if l < L - 1:  # gradient from the layer above for this chunk: dX = dG_{l+1} @ W_{l+1}
+                        dx = torch.matmul(dG[l + 1, t0:t0 + n].view(n * B, 4 * H), Wp[l + 1]).view(n, B, H)
+                        if masks[l + 1] is not None:
+                            dx = dx * masks[l + 1][t0:t0 + n]
+                        delta[l, t0:t0 + n] += dx
+                    d = delta[l]
+                    slots.append(_lib.BwdSlot(wt[l].data_ptr(), G[l, thi].data_ptr(), Cs[l, thi].data_ptr(),
+                                              d[thi].data_ptr(), d.stride(0), d.stride(1), dG[l, thi].data_ptr(),
+                                              ring[l].data_ptr(), dC[l].data_ptr(), thi & 1, n, int(thi < T - 1), 0))
+                arr = (_lib.BwdSlot * len(slots))(*slots)
+                _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots),
+                                                    max(s_.nsteps for s_ in slots), B, H, tag, int(hard), st))
+        grads = []
+        for l in range(L):
+            dg = dG[l].view(T * B, 4 * H)
+            if l == 0:
+                xin = x.detach().flatten(0, 1).to(dt)
+            else:
+                xin = Y[l - 1, 1:]
+                if masks[l] is not None:
+                    xin = xin * masks[l]
+                xin = xin.reshape(T * B, H)
+            dB = dg.sum(0)
+            grads += [torch.matmul(dg.t(), xin), torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), dB, dB]
+        dX = torch.matmul(dG[0].view(T * B, 4 * H), Wp[0]).view(T, B, -1) if need_dx else None
+        return (dX, None, None, None, None, None, *grads)

@@ -129,6 +129,35 @@ int caiman_lstm_fused_bwd(const void* R, const void* gates, const void* c, const
                           void* work, int64_t T, int64_t B, int64_t H, int dtype, int hard,
                           caiman_stream_t stream);
 
+/* ---- multi-layer ("wave") interface of the same kernels ------------------------------------ *
+ * One launch advances several independent recurrences (slots): a stack of L layers is run as a
+ * pipeline in which layer l works a chunk of timesteps behind layer l-1, so a sequence costs
+ * T + (L-1)*chunk dependent kernel boundaries instead of L*T.  f16 / bf16, H % 32 == 0.
+ *
+ * caiman_lstm_prepare : once per layer and pass. Re-lays R [4H,H] fragment-major into
+ *   weights_tiled (4H*H elements), clears the operand ring (2*pad32(B)*H elements forward,
+ *   2*pad32(B)*4H backward) and, forward: tiles the initial state h0 [B,H] into ring half 0;
+ *   backward: zeroes dC [B,H] f32.
+ * forward slot : pointers at the slot's FIRST timestep t0 of this call: gates row t0, c / y row t0
+ *   (inputs; outputs go to row t0+1 ...), parity = t0 & 1, nsteps = timesteps to run (<= n_launches).
+ * backward slot: pointers at the slot's LAST timestep t_hi of this call (rows walk downwards):
+ *   gates / c / delta / dG row t_hi, parity = t_hi & 1, has_next = (t_hi is not the final timestep). */
+typedef struct {
+  const void* weights_tiled; void* gates; void* c; void* y; void* ring;
+  int32_t parity; int32_t nsteps;
+} caiman_lstm_fwd_slot_t;
+typedef struct {
+  const void* weights_tiled; const void* gates; const void* c; const void* delta;
+  int64_t delta_stride_t; int64_t delta_stride_b; void* dG; void* ring; void* dC;
+  int32_t parity; int32_t nsteps; int32_t has_next; int32_t reserved;
+} caiman_lstm_bwd_slot_t;
+int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
+                        int64_t B, int64_t H, int dtype, int backward, caiman_stream_t stream);
+int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches,
+                         int64_t B, int64_t H, int dtype, int hard, caiman_stream_t stream);
+int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n_launches,
+                         int64_t B, int64_t H, int dtype, int hard, caiman_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
  * vendored; call sites training/caiman_asr_train/rnnt/model.py:228-238,425-434; CPU

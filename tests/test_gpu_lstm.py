@@ -165,3 +165,65 @@ def test_non_contiguous_delta_and_input_checks():
         lstm_cu.lstm_fused_fwd_soft(R.t(), gates, c, y)
     with pytest.raises(RuntimeError, match="CUDA"):
         lstm_cu.lstm_fused_fwd_soft(R.cpu(), gates, c, y)
+
+
+@pytest.mark.parametrize("T,B,I,H,L", [(5, 3, 16, 64, 2), (70, 5, 48, 64, 3), (33, 32, 32, 128, 6), (64, 40, 64, 256, 2)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layer_pipelined_stack_equals_per_layer_schedule(T, B, I, H, L, dtype):
+    """The chunked layer pipeline (custom_lstm/stack.py) runs the same kernels on the same operands in a
+    different order, so with dropout off it must reproduce the layer-by-layer schedule: outputs, states and
+    every gradient (bit-exact up to the summation order of the final weight-gradient GEMMs)."""
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    torch.manual_seed(T + H)
+    m = CustomLSTM(I, H, L, device=DEV)
+    x1 = torch.randn(T, B, I, device=DEV, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    h0 = torch.randn(L, B, H, device=DEV) * 0.3
+    c0 = torch.randn(L, B, H, device=DEV) * 0.3
+    w = torch.randn(T, B, H, device=DEV)
+    outs = []
+    for xin, pipe in ((x1, True), (x2, False)):
+        m.pipeline_layers = pipe
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=dtype):
+            y, (hn, cn), (ah, ac) = m(xin, (h0, c0))
+        (y.float() * w).sum().backward()
+        outs.append((y.float(), hn.float(), cn.float(), ah.float(), ac.float(), xin.grad.clone(),
+                     [p.grad.clone() for p in m.parameters()]))
+    a, b = outs
+    for i in range(5):
+        assert torch.equal(a[i], b[i]), i
+    assert torch.allclose(a[5], b[5], atol=1e-6, rtol=1e-3)
+    for ga, gb in zip(a[6], b[6]):
+        scale = gb.abs().max().item() + 1e-6
+        assert torch.allclose(ga, gb, atol=2e-2 * scale), (ga - gb).abs().max().item() / scale
+
+
+def test_layer_pipelined_stack_close_to_torch_lstm_and_dropout_mask_consistency():
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    cand, ref = _pair(3, 32, 64, torch.float32)
+    X = torch.randn(45, 7, 32, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        o2, (h2, c2), _ = cand(X)
+    o1, (h1, c1) = ref(X)
+    assert torch.allclose(o1, o2.float(), atol=4e-2) and torch.allclose(c1, c2.float(), atol=8e-2)
+    # with dropout the forward mask must be the one used in backward: d(sum y)/dx finite-difference check in bf16
+    # is too noisy, so check determinism of the pair instead: same seed -> same loss and same gradients
+    m = CustomLSTM(16, 64, 3, dropout=0.3, device=DEV)
+    x = torch.randn(40, 4, 16, device=DEV, requires_grad=True)
+    res = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        m.zero_grad()
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y, _, _ = m(x)
+        y.float().pow(2).sum().backward()
+        res.append((y.detach().clone(), x.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    m.eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_eval, _, _ = m(x)
+    assert not torch.equal(y_eval, res[0][0])  # dropout really was active in training mode

@@ -109,6 +109,41 @@ float run(const bf16* R, bf16* g, bf16* c, bf16* y, int T, int B, int H, int nst
   return ms * 1e3f / (3.f * T);
 }
 
+template <int MODE>
+float run_graph(const bf16* R, bf16* g, bf16* c, bf16* y, int T, int B, int H, hipStream_t st) {
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  hipGraph_t graph; hipGraphExec_t exec;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int t = 0; t < T; ++t)
+    hipLaunchKernelGGL((fwd_step<MODE, 8>), dim3(H / 4, (B + 31) / 32), dim3(256), 0, st, R, g + go * t, c + so * t, c + so * (t + 1),
+                       y + so * t, y + so * (t + 1), B, H);
+  CK(hipStreamEndCapture(st, &graph));
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(exec, st)); CK(hipStreamSynchronize(st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, st));
+  CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / (3.f * T);
+}
+
+__global__ void empty_kernel2(float* p) { if (p && threadIdx.x == 9999) p[0] = 1.f; }
+float run_graph_empty(int T, hipStream_t st) {
+  hipGraph_t graph; hipGraphExec_t exec;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int t = 0; t < T; ++t) hipLaunchKernelGGL(empty_kernel2, dim3(256), dim3(256), 0, st, (float*)nullptr);
+  CK(hipStreamEndCapture(st, &graph));
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(exec, st)); CK(hipStreamSynchronize(st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, st));
+  CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / (3.f * T);
+}
+
 int main(int argc, char** argv) {
   const int T = 400, B = argc > 1 ? atoi(argv[1]) : 32, H = 1024, NS = 4;
   bf16 *R, *g, *c, *y;
@@ -143,6 +178,10 @@ int main(int argc, char** argv) {
   printf("TILED h and R, no epilogue     : %.2f\n", run<195>(R, g, c, y, T, B, H, 1, st));
   printf("full, paired k-steps           : %.2f\n", run<23>(R, g, c, y, T, B, H, 1, st));
   printf("full, contiguous k per wave    : %.2f\n", run<39>(R, g, c, y, T, B, H, 1, st));
+  printf("GRAPH: empty kernels           : %.2f\n", run_graph_empty(T, st[0]));
+  printf("GRAPH: full TILED h and R      : %.2f\n", run_graph<199>(R, g, c, y, T, B, H, st[0]));
+  printf("GRAPH: TILED, no epilogue      : %.2f\n", run_graph<195>(R, g, c, y, T, B, H, st[0]));
+  printf("GRAPH: MFMA+LDS only           : %.2f\n", run_graph<0>(R, g, c, y, T, B, H, st[0]));
   printf("full, nontemporal R            : %.2f\n", run<15>(R, g, c, y, T, B, H, 1, st));
   printf("full, 2 independent streams    : %.2f per step-pair\n", run<7>(R, g, c, y, T, B, H, 2, st));
   printf("full, 4 independent streams    : %.2f per step-quad\n", run<7>(R, g, c, y, T, B, H, 4, st));
