@@ -241,14 +241,15 @@ def main():
         if not args.no_kernel_timing:
             summ = _lib.timing_summary()
             out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in summ.items()}
-            # Roofline of the dominant kernel (profiles/: lstm_bwd_step_mfma, ~35 % of GPU time): one
-            # launch = one backward timestep of one LSTM layer. HBM-bound by construction: the
-            # recurrent weights are re-streamed every step because L2 does not survive a kernel
-            # boundary. Algorithmic bytes per launch: rnnt_ext/cuda/lstm.py::_step_bytes.
+            # Roofline of the dominant kernel (profiles/: lstm_bwd_step_mfma): one launch = one backward
+            # timestep of every LSTM layer that is active in the layer pipeline (1..6 layers per launch).
+            # HBM-bound by construction: the recurrent weights are re-streamed every step because L2
+            # does not survive a kernel boundary. Algorithmic bytes per layer-step:
+            # rnnt_ext/cuda/lstm.py::_step_bytes; a launch carries the sum over its layers.
             if "lstm_bwd" in summ:
                 _, ms, launches, nbytes = summ["lstm_bwd"]
                 achieved = nbytes / (ms * 1e-3) / 1e9
-                out["roofline"] = {"kernel": "lstm_bwd_step_mfma (one backward LSTM timestep per launch)",
+                out["roofline"] = {"kernel": "lstm_bwd_step_mfma (one backward timestep of all pipelined LSTM layers per launch)",
                                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                    "avg_launch_us": ms * 1e3 / launches, "launches": launches,

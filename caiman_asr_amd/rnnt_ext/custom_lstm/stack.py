@@ -88,7 +88,8 @@ class StackFunction(torch.autograd.Function):
                                                 None, B, H, tag, 0, st))
         n_ch = (T + CHUNK - 1) // CHUNK
         es = G.element_size()
-        with _lib.timed("lstm_fwd", T * L, T * L * _step_bytes(B, H, es, False)):
+        sb = _step_bytes(B, H, es, False)
+        if True:
             for tau in range(n_ch + L - 1):
                 slots = []
                 for l in range(L):
@@ -104,8 +105,10 @@ class StackFunction(torch.autograd.Function):
                     slots.append(_lib.FwdSlot(wt[l].data_ptr(), G[l, t0].data_ptr(), Cs[l, t0].data_ptr(),
                                               Y[l, t0].data_ptr(), ring[l].data_ptr(), t0 & 1, n))
                 arr = (_lib.FwdSlot * len(slots))(*slots)
-                _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots),
-                                                    max(s_.nsteps for s_ in slots), B, H, tag, int(hard), st))
+                n_launch = max(s_.nsteps for s_ in slots)
+                with _lib.timed("lstm_fwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
+                    _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
+                                                        tag, int(hard), st))
         ctx.save_for_backward(x, G, Y, Cs, *Wp, *Rp, *[m for m in masks if m is not None])
         ctx.meta = (L, T, B, H, hard, [m is not None for m in masks], x.requires_grad)
         y_top = Y[L - 1, 1:]
@@ -140,7 +143,8 @@ class StackFunction(torch.autograd.Function):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
                                                 B, H, tag, 1, st))
         n_ch = (T + CHUNK - 1) // CHUNK
-        with _lib.timed("lstm_bwd", T * L, T * L * _step_bytes(B, H, G.element_size(), True)):
+        sb = _step_bytes(B, H, G.element_size(), True)
+        if True:
             for tau in range(n_ch + L - 1):
                 slots = []
                 for l in range(L - 1, -1, -1):
@@ -160,8 +164,10 @@ class StackFunction(torch.autograd.Function):
                                               d[thi].data_ptr(), d.stride(0), d.stride(1), dG[l, thi].data_ptr(),
                                               ring[l].data_ptr(), dC[l].data_ptr(), thi & 1, n, int(thi < T - 1), 0))
                 arr = (_lib.BwdSlot * len(slots))(*slots)
-                _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots),
-                                                    max(s_.nsteps for s_ in slots), B, H, tag, int(hard), st))
+                n_launch = max(s_.nsteps for s_ in slots)
+                with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
+                    _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
+                                                        tag, int(hard), st))
         grads = []
         for l in range(L):
             dg = dG[l].view(T * B, 4 * H)
