@@ -189,3 +189,63 @@ def test_lamb_step_matches_python_restatement():
     assert opt.last_step_applied.item() == 0
     for p, b in zip(params, before):
         assert torch.equal(p, b)
+
+
+def test_batch_split_step_equals_plain_step():
+    # training/tests/rnnt/test_batch_split.py:103-144 (loss and every gradient, rtol/atol 1e-4)
+    from argparse import Namespace
+
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers
+    from caiman_asr_amd.train_utils.batch_splitting import train_step_batch_split
+    from caiman_asr_amd.train_utils.core import train_step
+
+    mods = LossModifiers(delay_penalty=0.01, eos_penalty=0.0, star_penalty=1.0)
+    res = []
+    for split in (1, 2):
+        g, sd, cfg, m = build("tiny", joint_apex_transducer="pack", joint_apex_relu_dropout=True)
+        m.train()
+        V = int(g["n_classes"])
+        # 4 utterances: repeat the golden batch of 3 with one duplicate
+        idx = [0, 1, 2, 1]
+        x = torch.tensor(g["x"][:, idx], device=DEV)
+        xl, y, yl = torch.tensor(g["x_lens"][idx]), torch.tensor(g["y"][idx], device=DEV), torch.tensor(g["y_lens"][idx])
+        loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+        args = Namespace(grad_accumulation_batches=1, batch_split_factor=split, no_amp=True, num_gpus=1)
+        fn = train_step if split == 1 else train_step_batch_split
+        loss, nan, _ = fn(m, loss_fn, args, x, xl, y, yl, None, None, mods)
+        assert not nan
+        res.append((loss, {n: p.grad.clone() for n, p in m.named_parameters()}))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+    for n, ga in res[0][1].items():
+        assert torch.allclose(ga, res[1][1][n], rtol=1e-4, atol=1e-5), n
+
+
+def test_beam_expander_topk_and_pruning():
+    from caiman_asr_amd.rnnt.beam import BeamExpander
+
+    g, sd, cfg, m = build("mfma")
+    m.eval()
+    V = int(g["n_classes"])
+    x, xl = torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV)
+    with torch.no_grad():
+        f, _, _ = m.encode(x, xl)
+    be = BeamExpander(m, V - 1)
+    N = 5
+    frames = f[0, :N].unsqueeze(1).contiguous()          # 5 hypotheses on 5 frames of utterance 0
+    first = be.expand(frames, None, None)                 # SOS step
+    assert len(first) == N
+    lp, _ = be.log_probs(frames, None, None)
+    ref = torch.log_softmax(m.joint(frames, m.predict(None, None, add_sos=False)[0].expand(N, -1, -1))[:, 0, 0].float() / 1.4, -1)
+    assert torch.allclose(lp, ref, atol=1e-5)
+    for i, e in enumerate(first):
+        s, t = ref[i].topk(4)
+        keep = s >= s.max() - 1.5
+        assert torch.equal(e.tokens, t[keep].cpu()) and torch.allclose(e.scores, s[keep].cpu(), atol=1e-5)
+        assert e.blank_logp == pytest.approx(ref[i, V - 1].item(), abs=1e-5)
+        assert e.pred_state[0].shape == (cfg["pred_rnn_layers"], 1, cfg["pred_n_hid"])
+    # second expansion from the carried states with explicit last tokens
+    y_last = torch.stack([e.tokens[:1] for e in first]).to(DEV)
+    y_last = torch.where(y_last == V - 1, torch.zeros_like(y_last), y_last)
+    st = (torch.cat([e.pred_state[0] for e in first], 1), torch.cat([e.pred_state[1] for e in first], 1))
+    second = be.expand(frames, y_last, st)
+    assert len(second) == N and all(1 <= len(e.tokens) <= 4 for e in second)
