@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="weight-gradient GEMMs on the main stream")
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
     args = ap.parse_args()
 
@@ -125,6 +126,7 @@ def main():
     from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers, get_packing_meta_data
     from caiman_asr_amd.rnnt.model import RNNT
     from caiman_asr_amd.train_utils.distributed import FlatGradReducer, broadcast_parameters
+    from caiman_asr_amd.train_utils import overlap
     from caiman_asr_amd.train_utils.lr import lr_policy
     from caiman_asr_amd.train_utils.optimizer import build_optimizer
 
@@ -133,6 +135,10 @@ def main():
     torch.manual_seed(1234)  # identical initial weights on every rank (then broadcast anyway)
     model = RNNT(n_classes=N_CLASSES, **BASE_RNNT).to(dev)
     model.train()
+    model.overlap_weight_grads = not args.no_overlap
+    from caiman_asr_amd.rnnt_ext.custom_lstm import stack as lstm_stack
+
+    lstm_stack.OVERLAP_WEIGHT_GRADS = not args.no_overlap
     opt_args = Namespace(lr=4e-3, weight_decay=1e-2, beta1=0.9, beta2=0.999, clip_norm=1.0, ema=0.999)
     optimizer = build_optimizer(opt_args, model)
     initial_lrs = [g["lr"] for g in optimizer.param_groups]
@@ -165,6 +171,7 @@ def main():
             loss = loss_fn(logits, logit_lens, txt, txt_lens_d, meta["batch_offset"], meta["max_f_len"], loss_mods)
         del logits
         loss.backward()   # a NaN loss gives NaN gradients -> the optimiser skips the update on-device
+        overlap.wait_all()  # side-stream weight-gradient GEMMs must land before the gradients are used
         if reducer is not None:
             reducer.finish()
         optimizer.step(zero_grad=True)

@@ -102,9 +102,9 @@ _SIGS = {
          P, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_lstm_workspace_elems": ([I64, I64, I32], ctypes.c_int64),
-    "caiman_lstm_prepare": ([P, P, P, P, P, I64, I64, I32, I32, P], ctypes.c_int),
-    "caiman_lstm_wave_fwd": ([P, I32, I32, I64, I64, I32, I32, P], ctypes.c_int),
-    "caiman_lstm_wave_bwd": ([P, I32, I32, I64, I64, I32, I32, P], ctypes.c_int),
+    "caiman_lstm_prepare": ([P, P, P, P, P, I64, I64, I32, I32, I32, P], ctypes.c_int),
+    "caiman_lstm_wave_fwd": ([P, I32, I32, I64, I64, I32, I32, I32, P], ctypes.c_int),
+    "caiman_lstm_wave_bwd": ([P, I32, I32, I64, I64, I32, I32, I32, P], ctypes.c_int),
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),

@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256) void tile_R_fwd_kernel(const T* __restrict__ R
   out[i] = R[(int64_t)((n >> 2) * H + blk * 4 + (n & 3)) * H + s * 32 + kk];
 }
 
-// Rttile[((blk*nk4 + s)*16 + n)*32 + kk] = R[(s*32 + kk)*H + blk*16 + n]   (nk4 = 4H/32)
-template <typename T>
+// Rttile[((blk*nk4 + s)*16 + n)*32 + kk] = R[row(s*32 + kk)*H + blk*16 + n]   (nk4 = 4H/32)
+// row(k) = k for the reference gate layout [gate][unit]; for the interleaved layout [unit][gate]
+// the GEMM's K index is k = unit*4 + gate, i.e. row(k) = (k & 3)*H + (k >> 2).
+template <typename T, bool IL>
 __global__ __launch_bounds__(256) void tile_Rt_bwd_kernel(const T* __restrict__ R, T* __restrict__ out, int H) {
   __shared__ T t[32][17];
   const int nk4 = (4 * H) >> 5;
@@ -172,7 +174,9 @@ __global__ __launch_bounds__(256) void tile_Rt_bwd_kernel(const T* __restrict__ 
   // read R[s*32 + kk][blk*16 + n] : 32 rows x 16 cols
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int kk = e >> 4, n = e & 15;
-    t[kk][n] = R[(int64_t)(s * 32 + kk) * H + blk * 16 + n];
+    const int k = s * 32 + kk;
+    const int row = IL ? (k & 3) * H + (k >> 2) : k;
+    t[kk][n] = R[(int64_t)row * H + blk * 16 + n];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 512; e += 256) {
@@ -229,7 +233,10 @@ struct BwdSlots {
 // ---- forward step: grid (H/4, ceil(B/32), slots), 256 threads = 4 waves -----------------------
 //   output tile: 32 batch rows x 16 gate columns (4 gates x 4 hidden units); the H/32 k-steps
 //   are dealt round-robin to the 4 waves; NK = k-steps per wave (0 = runtime loop).
-template <typename T, bool HARD, int NK>
+// IL: gates are stored [B, H, 4] (unit-major, the 4 gates of a unit adjacent) instead of the reference's
+// [B, 4, H]: the epilogue then moves one 8-byte vector per (row, unit) instead of four 2-byte elements a
+// whole H apart (PMC: the scattered form fetched ~40 % more HBM bytes than the algorithmic count).
+template <typename T, bool HARD, int NK, bool IL>
 __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int step, int B, int H) {
   using frag = typename frag8<T>::type;
   __shared__ float tile[4][2][16][17];
@@ -254,12 +261,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int ste
   const int eb = tid >> 2, eu = tid & 3;
   const int be = m0 + eb, ne = j0 + eu;
   const bool ep = (tid < 128) && (be < B);
-  const int64_t gb = (int64_t)be * 4 * H + ne;
+  const int64_t gb = IL ? ((int64_t)be * H + ne) * 4 : (int64_t)be * 4 * H + ne;
+  const int64_t gstep = IL ? 1 : H;
+  using g4 = __attribute__((ext_vector_type(4))) T;
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
   float cprev = 0.f;
   if (ep) {
+    if constexpr (IL) {
+      const g4 v = *reinterpret_cast<const g4*>(g + gb);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pre[q] = static_cast<float>(g[gb + (int64_t)q * H]);
+      for (int q = 0; q < 4; ++q) pre[q] = static_cast<float>(v[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[q] = static_cast<float>(g[gb + (int64_t)q * gstep]);
+    }
     cprev = static_cast<float>(c0[(int64_t)be * H + ne]);
   }
 
@@ -315,15 +330,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int ste
   h_out[tiled_index(be, ne, nk)] = yv;  // what the next step reads
   y1[(int64_t)be * H + ne] = yv;
   c1[(int64_t)be * H + ne] = static_cast<T>(c);
-  g[gb] = static_cast<T>(i);
-  g[gb + H] = static_cast<T>(f);
-  g[gb + 2 * (int64_t)H] = static_cast<T>(gg);
-  g[gb + 3 * (int64_t)H] = static_cast<T>(o);
+  if constexpr (IL) {
+    g4 v;
+    v[0] = static_cast<T>(i); v[1] = static_cast<T>(f); v[2] = static_cast<T>(gg); v[3] = static_cast<T>(o);
+    *reinterpret_cast<g4*>(g + gb) = v;
+  } else {
+    g[gb] = static_cast<T>(i);
+    g[gb + H] = static_cast<T>(f);
+    g[gb + 2 * (int64_t)H] = static_cast<T>(gg);
+    g[gb + 3 * (int64_t)H] = static_cast<T>(o);
+  }
 }
 
 // ---- backward step: grid (H/16, ceil(B/32), slots), 1024 threads = 16 waves ---------------------
 //   dh tile: 32 batch rows x 16 hidden units, K = 4H dealt round-robin to the 16 waves.
-template <typename T, bool HARD, int NK>
+template <typename T, bool HARD, int NK, bool IL>
 __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int step, int B, int H) {
   using frag = typename frag8<T>::type;
   __shared__ float tile[16][2][16][17];
@@ -350,14 +371,21 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int st
   const int eb = tid >> 4, eu = tid & 15;  // 32 rows x 16 units on the first 512 threads
   const int be = m0 + eb, ne = n0 + eu;
   const bool ep = (tid < 512) && (be < B);
-  const int64_t gb = (int64_t)be * 4 * H + ne;
+  const int64_t gb = IL ? ((int64_t)be * H + ne) * 4 : (int64_t)be * 4 * H + ne;
+  using g4 = __attribute__((ext_vector_type(4))) T;
   float dy = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go_ = 0.f, cp = 0.f, cc = 0.f, dcf = 0.f;
   if (ep) {
     dy = static_cast<float>(delta[(int64_t)be * d_sb + ne]);
-    gi = static_cast<float>(g[gb]);
-    gf = static_cast<float>(g[gb + H]);
-    gg = static_cast<float>(g[gb + 2 * (int64_t)H]);
-    go_ = static_cast<float>(g[gb + 3 * (int64_t)H]);
+    if constexpr (IL) {
+      const g4 v = *reinterpret_cast<const g4*>(g + gb);
+      gi = static_cast<float>(v[0]); gf = static_cast<float>(v[1]);
+      gg = static_cast<float>(v[2]); go_ = static_cast<float>(v[3]);
+    } else {
+      gi = static_cast<float>(g[gb]);
+      gf = static_cast<float>(g[gb + H]);
+      gg = static_cast<float>(g[gb + 2 * (int64_t)H]);
+      go_ = static_cast<float>(g[gb + 3 * (int64_t)H]);
+    }
     cp = static_cast<float>(c_prev[(int64_t)be * H + ne]);
     cc = static_cast<float>(c_cur[(int64_t)be * H + ne]);
     dcf = dC[(int64_t)be * H + ne];
@@ -415,15 +443,22 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int st
   const T vF = static_cast<T>(dc * cp * Act<float, HARD>::sigm_prime(gf));
   const T vG = static_cast<T>(dc * gi * Act<float, HARD>::tanh_prime(gg));
   const T vO = static_cast<T>(dy * ct * Act<float, HARD>::sigm_prime(go_));
-  // tiled copy for the next (earlier-in-time) step
-  dG_out[tiled_index(be, ne, nk4)] = vI;
-  dG_out[tiled_index(be, H + ne, nk4)] = vF;
-  dG_out[tiled_index(be, 2 * H + ne, nk4)] = vG;
-  dG_out[tiled_index(be, 3 * H + ne, nk4)] = vO;
-  dG[gb] = vI;
-  dG[gb + H] = vF;
-  dG[gb + 2 * (int64_t)H] = vG;
-  dG[gb + 3 * (int64_t)H] = vO;
+  if constexpr (IL) {
+    g4 v;
+    v[0] = vI; v[1] = vF; v[2] = vG; v[3] = vO;
+    *reinterpret_cast<g4*>(dG_out + tiled_index(be, ne * 4, nk4)) = v;  // K index = unit*4 + gate
+    *reinterpret_cast<g4*>(dG + gb) = v;
+  } else {
+    // tiled copy for the next (earlier-in-time) step
+    dG_out[tiled_index(be, ne, nk4)] = vI;
+    dG_out[tiled_index(be, H + ne, nk4)] = vF;
+    dG_out[tiled_index(be, 2 * H + ne, nk4)] = vG;
+    dG_out[tiled_index(be, 3 * H + ne, nk4)] = vO;
+    dG[gb] = vI;
+    dG[gb + H] = vF;
+    dG[gb + 2 * (int64_t)H] = vG;
+    dG[gb + 3 * (int64_t)H] = vO;
+  }
   dC[(int64_t)be * H + ne] = dc * gf;
 }
 
@@ -432,12 +467,12 @@ constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_
 
 inline int64_t pad32(int64_t b) { return (b + 31) / 32 * 32; }
 
-template <typename T, bool HARD>
+template <typename T, bool HARD, bool IL>
 int launch_fwd_waves(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s) {
   const int nkw = (int)(((H >> 5) + 3) / 4);  // k-steps per wave
   const dim3 grid((unsigned)(H / 4), (unsigned)((B + 31) / 32), (unsigned)n_slots);
   for (int i = 0; i < n_launches; ++i) {
-#define CAIMAN_FWD(NKV) hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD, NKV>), grid, dim3(256), 0, s, w, i, (int)B, (int)H)
+#define CAIMAN_FWD(NKV) hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD, NKV, IL>), grid, dim3(256), 0, s, w, i, (int)B, (int)H)
     switch (nkw) {
       case 1: CAIMAN_FWD(1); break;
       case 2: CAIMAN_FWD(2); break;
@@ -452,12 +487,12 @@ int launch_fwd_waves(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t 
   return check_launch("lstm forward wave");
 }
 
-template <typename T, bool HARD>
+template <typename T, bool HARD, bool IL>
 int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s) {
   const int nkw = (int)(((4 * H >> 5) + 15) / 16);
   const dim3 grid((unsigned)(H / 16), (unsigned)((B + 31) / 32), (unsigned)n_slots);
   for (int i = 0; i < n_launches; ++i) {
-#define CAIMAN_BWD(NKV) hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD, NKV>), grid, dim3(1024), 0, s, w, i, (int)B, (int)H)
+#define CAIMAN_BWD(NKV) hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD, NKV, IL>), grid, dim3(1024), 0, s, w, i, (int)B, (int)H)
     switch (nkw) {
       case 1: CAIMAN_BWD(1); break;
       case 2: CAIMAN_BWD(2); break;
@@ -480,10 +515,11 @@ int prepare_fwd(const T* R, const T* h0, T* Rtile, T* hring, int64_t B, int64_t 
 }
 
 template <typename T>
-int prepare_bwd(const T* R, T* Rttile, T* dring, float* dC, int64_t B, int64_t H, hipStream_t s) {
+int prepare_bwd(const T* R, T* Rttile, T* dring, float* dC, int64_t B, int64_t H, hipStream_t s, bool il = false) {
   if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * pad32(B) * 4 * H), s) != hipSuccess) return check_launch("lstm prepare memset");
   if (hipMemsetAsync(dC, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return check_launch("lstm prepare memset");
-  hipLaunchKernelGGL((tile_Rt_bwd_kernel<T>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
+  if (il) hipLaunchKernelGGL((tile_Rt_bwd_kernel<T, true>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
+  else hipLaunchKernelGGL((tile_Rt_bwd_kernel<T, false>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
   return check_launch("lstm prepare backward");
 }
 
@@ -502,7 +538,7 @@ int run_fwd(const T* R, T* gates, T* c, T* y, T* work, int64_t Tn, int64_t B, in
         const int n = (int)std::min<int64_t>(4096, Tn - t0);
         w.g[0] = gates + go * t0; w.c[0] = c + so * t0; w.y[0] = y + so * t0;
         w.parity[0] = (int)(t0 & 1); w.nsteps[0] = n;
-        if (int e = launch_fwd_waves<T, HARD>(w, 1, n, B, H, s)) return e;
+        if (int e = launch_fwd_waves<T, HARD, false>(w, 1, n, B, H, s)) return e;
       }
       return CAIMAN_OK;
     }
@@ -529,7 +565,7 @@ int run_bwd(const T* R, const T* gates, const T* c, const T* delta, int64_t d_st
         const int n = (int)std::min<int64_t>(4096, thi + 1);
         w.g[0] = gates + go * thi; w.c[0] = c + so * thi; w.delta[0] = delta + d_st * thi; w.dG[0] = dG + go * thi;
         w.parity[0] = (int)(thi & 1); w.nsteps[0] = n; w.has_in0[0] = thi < Tn - 1;
-        if (int e = launch_bwd_waves<T, HARD>(w, 1, n, B, H, s)) return e;
+        if (int e = launch_bwd_waves<T, HARD, false>(w, 1, n, B, H, s)) return e;
       }
       return CAIMAN_OK;
     }
@@ -555,21 +591,22 @@ extern "C" int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backwar
 
 // ---- multi-layer ("wave") interface -----------------------------------------------------------------
 extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
-                                   int64_t B, int64_t H, int dtype, int backward, caiman_stream_t stream) {
+                                   int64_t B, int64_t H, int dtype, int backward, int gate_layout,
+                                   caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(B >= 1 && H >= 32 && H % 32 == 0, "lstm_prepare: H must be a positive multiple of 32 (got %lld)", (long long)H);
   CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "lstm_prepare: the wave interface is f16 / bf16 only");
   CAIMAN_CHECK(R && weights_tiled && ring && (backward ? dC != nullptr : h0 != nullptr), "lstm_prepare: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == CAIMAN_BF16)
-    return backward ? prepare_bwd<bf16_t>((const bf16_t*)R, (bf16_t*)weights_tiled, (bf16_t*)ring, (float*)dC, B, H, s)
+    return backward ? prepare_bwd<bf16_t>((const bf16_t*)R, (bf16_t*)weights_tiled, (bf16_t*)ring, (float*)dC, B, H, s, gate_layout != 0)
                     : prepare_fwd<bf16_t>((const bf16_t*)R, (const bf16_t*)h0, (bf16_t*)weights_tiled, (bf16_t*)ring, B, H, s);
-  return backward ? prepare_bwd<f16_t>((const f16_t*)R, (f16_t*)weights_tiled, (f16_t*)ring, (float*)dC, B, H, s)
+  return backward ? prepare_bwd<f16_t>((const f16_t*)R, (f16_t*)weights_tiled, (f16_t*)ring, (float*)dC, B, H, s, gate_layout != 0)
                   : prepare_fwd<f16_t>((const f16_t*)R, (const f16_t*)h0, (f16_t*)weights_tiled, (f16_t*)ring, B, H, s);
 }
 
 extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches, int64_t B,
-                                    int64_t H, int dtype, int hard, caiman_stream_t stream) {
+                                    int64_t H, int dtype, int hard, int gate_layout, caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(slots && n_slots >= 1 && n_slots <= kMaxSlots, "lstm_wave_fwd: 1..%d slots", kMaxSlots);
   CAIMAN_CHECK(B >= 1 && B <= 32 * 65535 && H >= 32 && H % 32 == 0, "lstm_wave_fwd: bad extents");
@@ -588,14 +625,17 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
       w.y[i] = (T*)slots[i].y; w.hring[i] = (T*)slots[i].ring; w.parity[i] = slots[i].parity & 1;
       w.nsteps[i] = slots[i].nsteps;
     }
-    return hard ? launch_fwd_waves<T, true>(w, n_slots, n_launches, B, H, s)
-                : launch_fwd_waves<T, false>(w, n_slots, n_launches, B, H, s);
+    if (gate_layout)
+      return hard ? launch_fwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
+                  : launch_fwd_waves<T, false, true>(w, n_slots, n_launches, B, H, s);
+    return hard ? launch_fwd_waves<T, true, false>(w, n_slots, n_launches, B, H, s)
+                : launch_fwd_waves<T, false, false>(w, n_slots, n_launches, B, H, s);
   };
   return dtype == CAIMAN_BF16 ? go_(bf16_t{}) : go_(f16_t{});
 }
 
 extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n_launches, int64_t B,
-                                    int64_t H, int dtype, int hard, caiman_stream_t stream) {
+                                    int64_t H, int dtype, int hard, int gate_layout, caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(slots && n_slots >= 1 && n_slots <= kMaxSlots, "lstm_wave_bwd: 1..%d slots", kMaxSlots);
   CAIMAN_CHECK(B >= 1 && B <= 32 * 65535 && H >= 32 && H % 32 == 0, "lstm_wave_bwd: bad extents");
@@ -615,8 +655,11 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
       w.dG[i] = (T*)slots[i].dG; w.dring[i] = (T*)slots[i].ring; w.dC[i] = (float*)slots[i].dC;
       w.parity[i] = slots[i].parity & 1; w.nsteps[i] = slots[i].nsteps; w.has_in0[i] = slots[i].has_next ? 1 : 0;
     }
-    return hard ? launch_bwd_waves<T, true>(w, n_slots, n_launches, B, H, s)
-                : launch_bwd_waves<T, false>(w, n_slots, n_launches, B, H, s);
+    if (gate_layout)
+      return hard ? launch_bwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
+                  : launch_bwd_waves<T, false, true>(w, n_slots, n_launches, B, H, s);
+    return hard ? launch_bwd_waves<T, true, false>(w, n_slots, n_launches, B, H, s)
+                : launch_bwd_waves<T, false, false>(w, n_slots, n_launches, B, H, s);
   };
   return dtype == CAIMAN_BF16 ? go_(bf16_t{}) : go_(f16_t{});
 }

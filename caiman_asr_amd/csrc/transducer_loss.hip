@@ -306,20 +306,41 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
   const bool right_any = right_term || !last_t;
   const A right_add = right_term ? star_pen : beta_Tp1U + star_pen;
 
+  // The result is rounded to T: for the 16-bit types the hardware exponential (v_exp_f32, ~1 ulp f32) is exact
+  // after rounding; f32 / f64 keep the libm exp.  The bulk of the row takes one exp per element: only the
+  // label column, the blank column and star rows subtract a second / third term.
+  auto fexp = [](A v) -> A {
+    if constexpr (sizeof(T) == 2) return __expf(v);
+    else return exp(v);
+  };
+  const A base = common + beta_TU - den;  // grad + beta_TU = x + base
   auto one = [&](A xv, int64_t h) -> A {
-    const A grad = common + (den_ok ? xv - den : static_cast<A>(NAN));
-    A g = exp(grad + beta_TU);
-    if (not_top && (up_all || h == labUp1)) g -= exp(grad + beta_TUp1);
-    if (right_any && (right_all || h == p.blank)) g -= exp(grad + right_add);
+    if (!den_ok) return static_cast<A>(NAN);
+    A g = fexp(xv + base);
+    if (not_top && (up_all || h == labUp1)) g -= fexp(xv + (common - den + beta_TUp1));
+    if (right_any && (right_all || h == p.blank)) g -= fexp(xv + (common - den + right_add));
     return g;
   };
 
-  for (int64_t c = lane; c < nfull; c += kWave) {
-    const Vt v = *reinterpret_cast<const Vt*>(rx + c * VEC);
-    Vt o;
+  // 4 independent 16-byte loads in flight per lane before the first exp (HBM-bound streaming kernel)
+  constexpr int UN = 4;
+  for (int64_t c0 = lane; c0 < nfull; c0 += UN * kWave) {
+    Vt v[UN];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.v[j] = static_cast<T>(one(static_cast<A>(v.v[j]), c * VEC + j));
-    *reinterpret_cast<Vt*>(gx + c * VEC) = o;
+    for (int k = 0; k < UN; ++k) {
+      const int64_t c = c0 + (int64_t)k * kWave;
+      if (c < nfull) v[k] = *reinterpret_cast<const Vt*>(rx + c * VEC);
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int64_t c = c0 + (int64_t)k * kWave;
+      if (c < nfull) {
+        Vt o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = static_cast<T>(one(static_cast<A>(v[k].v[j]), c * VEC + j));
+        *reinterpret_cast<Vt*>(gx + c * VEC) = o;
+      }
+    }
   }
   for (int64_t h = nfull * VEC + lane; h < p.V; h += kWave) gx[h] = static_cast<T>(one(static_cast<A>(rx[h]), h));
 }

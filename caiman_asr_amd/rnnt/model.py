@@ -56,6 +56,9 @@ class RNNT(nn.Module):
             "joint_pred": joint_pred_lr_factor, "joint_net": joint_net_lr_factor}
         self.pred_n_hid = pred_n_hid
         self.enc_stack_time_factor = enc_stack_time_factor
+        # opt-in: joint_fc's weight gradient runs on a side stream (train_utils/overlap.py); the training
+        # loop must call overlap.wait_all() before it reads the gradients
+        self.overlap_weight_grads = False
 
         common = dict(forget_gate_bias=forget_gate_bias, custom_lstm=custom_lstm, quantize=quantize,
                       hidden_hidden_bias_scale=hidden_hidden_bias_scale, weights_init_scale=weights_init_scale,
@@ -165,6 +168,10 @@ class RNNT(nn.Module):
             h = self.apex_joint(f, g, f_len, g_len, batch_offset=batch_offset, packed_batch=packed_batch)
             if not self.apex_joint.relu:
                 h = self.relu_drop(h)
+        if self.overlap_weight_grads and self.training and h.is_cuda and torch.is_grad_enabled():
+            from caiman_asr_amd.train_utils.overlap import linear_overlapped
+
+            return linear_overlapped(h, self.joint_fc.weight, self.joint_fc.bias)
         return self.joint_fc(h)
 
     @staticmethod

@@ -23,6 +23,20 @@ from caiman_asr_amd import _lib
 from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 
 CHUNK = 32
+# opt-in (set by the training loop): weight gradients are computed on the side stream and added straight into
+# `param.grad` (train_utils/overlap.py); the loop must call overlap.wait_all() before reading gradients.
+OVERLAP_WEIGHT_GRADS = False
+INTERLEAVED = 1  # gate layout used INSIDE the pipeline: [.., H, 4] (see include/caiman_rnnt.h)
+
+
+def _perm_rows(w, H):
+    """rows [gate][unit] -> [unit][gate] (works for [4H, K] matrices and [4H] vectors)."""
+    return w.reshape(4, H, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
+
+
+def _unperm_rows(w, H):
+    """inverse of _perm_rows."""
+    return w.reshape(H, 4, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
 
 
 def eligible(x: torch.Tensor, hidden_size: int, num_layers: int, gate_dtype) -> bool:
@@ -58,11 +72,13 @@ class StackFunction(torch.autograd.Function):
         L = len(params) // 4
         Ws, Rs, bWs, bRs = params[0::4], params[1::4], params[2::4], params[3::4]
         T, B, _ = x.shape
-        H = Rs[0].shape[1]
         dev = x.device
         lib = _lib.lib()
         # layer 0: every timestep's input contribution in one GEMM (autocast decides the gate dtype)
-        g0 = torch.addmm(bWs[0] + bRs[0], x.flatten(0, 1), Ws[0].t())
+        H = Rs[0].shape[1]
+        # the pipeline keeps gates / dG unit-major ([.., H, 4]): permute the ROWS of W_ih and of the biases once
+        # per call (R keeps its layout: the tiling kernels absorb the permutation)
+        g0 = torch.addmm(_perm_rows(bWs[0] + bRs[0], H), x.flatten(0, 1), _perm_rows(Ws[0], H).t())
         dt = g0.dtype
         tag = _lib.dtype_tag(dt)
         G = torch.empty((L, T, B, 4 * H), dtype=dt, device=dev)
@@ -73,8 +89,8 @@ class StackFunction(torch.autograd.Function):
         Y[:, 0].copy_(h0)
         Cs[:, 0].copy_(c0)
         Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [W.to(dt) for W in Ws]
-        bias = [(bWs[l] + bRs[l]).to(dt) for l in range(L)]
+        Wp = [_perm_rows(W, H).to(dt) for W in Ws]
+        bias = [_perm_rows(bWs[l] + bRs[l], H).to(dt) for l in range(L)]
         masks: List[Optional[torch.Tensor]] = [None] * L
         if training and p_drop > 0.0:
             for l in range(1, L):
@@ -85,7 +101,7 @@ class StackFunction(torch.autograd.Function):
         st = _lib.stream()
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]), _lib.ptr(ring[l]),
-                                                None, B, H, tag, 0, st))
+                                                None, B, H, tag, 0, INTERLEAVED, st))
         n_ch = (T + CHUNK - 1) // CHUNK
         es = G.element_size()
         sb = _step_bytes(B, H, es, False)
@@ -108,9 +124,10 @@ class StackFunction(torch.autograd.Function):
                 n_launch = max(s_.nsteps for s_ in slots)
                 with _lib.timed("lstm_fwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
                     _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
-                                                        tag, int(hard), st))
+                                                        tag, int(hard), INTERLEAVED, st))
         ctx.save_for_backward(x, G, Y, Cs, *Wp, *Rp, *[m for m in masks if m is not None])
         ctx.meta = (L, T, B, H, hard, [m is not None for m in masks], x.requires_grad)
+        ctx.params = params
         y_top = Y[L - 1, 1:]
         all_h, all_c = Y[:, 1:], Cs[:, 1:]
         ctx.mark_non_differentiable(all_c)
@@ -141,7 +158,7 @@ class StackFunction(torch.autograd.Function):
         dC = _Scratch.get("bc", L * B * H, torch.float32, dev).view(L, -1)
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
-                                                B, H, tag, 1, st))
+                                                B, H, tag, 1, INTERLEAVED, st))
         n_ch = (T + CHUNK - 1) // CHUNK
         sb = _step_bytes(B, H, G.element_size(), True)
         if True:
@@ -167,9 +184,8 @@ class StackFunction(torch.autograd.Function):
                 n_launch = max(s_.nsteps for s_ in slots)
                 with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
                     _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
-                                                        tag, int(hard), st))
-        grads = []
-        for l in range(L):
+                                                        tag, int(hard), INTERLEAVED, st))
+        def weight_grads(l):
             dg = dG[l].view(T * B, 4 * H)
             if l == 0:
                 xin = x.detach().flatten(0, 1).to(dt)
@@ -178,7 +194,27 @@ class StackFunction(torch.autograd.Function):
                 if masks[l] is not None:
                     xin = xin * masks[l]
                 xin = xin.reshape(T * B, H)
-            dB = dg.sum(0)
-            grads += [torch.matmul(dg.t(), xin), torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), dB, dB]
+            dB = _unperm_rows(dg.sum(0), H)
+            return [_unperm_rows(torch.matmul(dg.t(), xin), H),
+                    _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
+
         dX = torch.matmul(dG[0].view(T * B, 4 * H), Wp[0]).view(T, B, -1) if need_dx else None
+        if OVERLAP_WEIGHT_GRADS:
+            from caiman_asr_amd.train_utils import overlap
+
+            main = torch.cuda.current_stream()
+            side = overlap.side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for l in range(L):
+                    for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], weight_grads(l)):
+                        if p_.requires_grad:
+                            overlap._accumulate(p_, g_)
+            for t_ in (dG, Y, x, *[m for m in masks if m is not None]):
+                t_.record_stream(side)
+            overlap._pending = True
+            return (dX, None, None, None, None, None, *([None] * (4 * L)))
+        grads = []
+        for l in range(L):
+            grads += weight_grads(l)
         return (dX, None, None, None, None, None, *grads)

@@ -1,0 +1,72 @@
+"""Side-stream execution of weight-gradient GEMMs.
+
+In the backward pass only the INPUT gradients are on the critical path; the weight gradients are needed just
+before the optimiser (or the all-reduce).  The LSTM backward that follows the joint's backward is a chain of
+latency-bound step kernels that leaves the matrix cores idle, so the big `dW = dYᵀ·X` GEMMs are launched on a
+second HIP stream and accumulate straight into the parameter's gradient (a view of the flat arena).
+`wait_all()` must be called before the gradients are consumed (reducer.finish() / optimizer.step()).
+"""
+import torch
+import torch.nn.functional as F
+
+_side = {}
+_pending = False
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def wait_all():
+    """Make the current stream wait for every side-stream gradient GEMM issued so far."""
+    global _pending
+    if _pending:
+        for s in _side.values():
+            torch.cuda.current_stream().wait_stream(s)
+        _pending = False
+
+
+def _accumulate(param, value):
+    if param.grad is None:
+        param.grad = torch.zeros_like(param)
+    param.grad.add_(value.to(param.grad.dtype))
+
+
+class _LinearOverlapped(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.bias = bias
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        global _pending
+        x, weight = ctx.saved_tensors
+        bias = ctx.bias
+        dy = dy.contiguous()
+        dx = torch.matmul(dy, weight.to(dy.dtype)) if ctx.needs_input_grad[0] else None
+        main = torch.cuda.current_stream()
+        side = side_stream(dy.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            x2 = x.reshape(-1, x.shape[-1]).to(dy.dtype)
+            _accumulate(weight, torch.matmul(dy2.t(), x2))
+            if bias is not None:
+                _accumulate(bias, dy2.sum(0))
+        for t in (dy, x):
+            t.record_stream(side)
+        _pending = True
+        return dx, None, None
+
+
+def linear_overlapped(x, weight, bias):
+    """F.linear whose weight / bias gradients are produced on the side stream and added to `.grad` directly
+    (autograd sees no gradient for them): call `wait_all()` before using the gradients."""
+    return _LinearOverlapped.apply(x, weight, bias)

@@ -151,12 +151,19 @@ typedef struct {
   int64_t delta_stride_t; int64_t delta_stride_b; void* dG; void* ring; void* dC;
   int32_t parity; int32_t nsteps; int32_t has_next; int32_t reserved;
 } caiman_lstm_bwd_slot_t;
+/* gate_layout: 0 = the reference's gates / dG layout [B, 4, H] (gate-major, lstm.cu:99-102);
+ *              1 = interleaved [B, H, 4] (the 4 gates of a hidden unit adjacent): an internal layout of the
+ *                  stack pipeline (the caller permutes the rows of W_ih / biases accordingly) that turns the
+ *                  epilogue's 2-byte strided accesses into 8-byte vectors. */
 int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
-                        int64_t B, int64_t H, int dtype, int backward, caiman_stream_t stream);
+                        int64_t B, int64_t H, int dtype, int backward, int gate_layout,
+                        caiman_stream_t stream);
 int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches,
-                         int64_t B, int64_t H, int dtype, int hard, caiman_stream_t stream);
+                         int64_t B, int64_t H, int dtype, int hard, int gate_layout,
+                         caiman_stream_t stream);
 int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n_launches,
-                         int64_t B, int64_t H, int dtype, int hard, caiman_stream_t stream);
+                         int64_t B, int64_t H, int dtype, int hard, int gate_layout,
+                         caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
