@@ -116,7 +116,14 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # CAIMAN_DIST_BACKEND=gloo is a rehearsal aid (several ranks sharing one GPU); the real path is RCCL
+        backend = os.environ.get("CAIMAN_DIST_BACKEND", "nccl")
+        n_dev = torch.cuda.device_count()
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(n_dev, 1)
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

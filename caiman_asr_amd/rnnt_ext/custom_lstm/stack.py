@@ -22,7 +22,12 @@ import torch
 from caiman_asr_amd import _lib
 from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 
-CHUNK = 32
+CHUNK = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK", "32"))  # timesteps per pipeline chunk, shallow stacks
+CHUNK_DEEP = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK_DEEP", "32"))  # stacks of >= 4 layers
+
+
+def _chunk(L):
+    return CHUNK_DEEP if L >= 4 else CHUNK
 # opt-in (set by the training loop): weight gradients are computed on the side stream and added straight into
 # `param.grad` (train_utils/overlap.py); the loop must call overlap.wait_all() before reading gradients.
 OVERLAP_WEIGHT_GRADS = False
@@ -102,7 +107,8 @@ class StackFunction(torch.autograd.Function):
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]), _lib.ptr(ring[l]),
                                                 None, B, H, tag, 0, INTERLEAVED, st))
-        n_ch = (T + CHUNK - 1) // CHUNK
+        CH = _chunk(L)
+        n_ch = (T + CH - 1) // CH
         es = G.element_size()
         sb = _step_bytes(B, H, es, False)
         if True:
@@ -112,7 +118,7 @@ class StackFunction(torch.autograd.Function):
                     k = tau - l
                     if k < 0 or k >= n_ch:
                         continue
-                    t0, n = k * CHUNK, min(CHUNK, T - k * CHUNK)
+                    t0, n = k * CH, min(CH, T - k * CH)
                     if l >= 1:  # input GEMM of this layer's chunk on what layer l-1 produced last tick
                         xin = Y[l - 1, 1 + t0:1 + t0 + n]
                         if masks[l] is not None:
@@ -159,7 +165,8 @@ class StackFunction(torch.autograd.Function):
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
                                                 B, H, tag, 1, INTERLEAVED, st))
-        n_ch = (T + CHUNK - 1) // CHUNK
+        CH = _chunk(L)
+        n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), True)
         if True:
             for tau in range(n_ch + L - 1):
@@ -169,7 +176,7 @@ class StackFunction(torch.autograd.Function):
                     if j < 0 or j >= n_ch:
                         continue
                     k = n_ch - 1 - j
-                    t0, n = k * CHUNK, min(CHUNK, T - k * CHUNK)
+                    t0, n = k * CH, min(CH, T - k * CH)
                     thi = t0 + n - 1
                     if l < L - 1:  # gradient from the layer above for this chunk: dX = dG_{l+1} @ W_{l+1}
                         dx = torch.matmul(dG[l + 1, t0:t0 + n].view(n * B, 4 * H), Wp[l + 1]).view(n, B, H)

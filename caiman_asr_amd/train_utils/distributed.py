@@ -26,6 +26,7 @@ class FlatGradReducer:
         self.flat = flat_grad
         self.overlap = overlap and flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
+        self.main_stream = torch.cuda.current_stream() if self.overlap else None
         # cut buckets from the tail of the arena
         order = sorted(range(len(params)), key=lambda i: offsets[i], reverse=True)
         self.buckets = []  # (start, end, n_params)
@@ -51,9 +52,17 @@ class FlatGradReducer:
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            # gradients produced on the side stream (train_utils/overlap.py) bypass autograd's accumulation:
+            # they report here instead, and the collective then also waits for the side stream
+            from caiman_asr_amd.train_utils import overlap
+
+            self._overlap = overlap
+            overlap.register_grad_ready_callback(self._on_grad)
 
     # ---- per-step protocol: backward() ... finish() ---------------------------------------
     def _on_grad(self, p):
+        if id(p) not in self.param_bucket:
+            return
         b = self.param_bucket[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -67,6 +76,9 @@ class FlatGradReducer:
         chunk = self.flat[s:e]
         if self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            self.comm_stream.wait_stream(self.main_stream)
+            for s_ in (self._overlap.side_streams() if getattr(self, "_overlap", None) else ()):
+                self.comm_stream.wait_stream(s_)
             with torch.cuda.stream(self.comm_stream):
                 self._handles.append(dist.all_reduce(chunk, group=self.group, async_op=True))
         else:

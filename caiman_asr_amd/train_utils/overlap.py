@@ -11,6 +11,19 @@ import torch.nn.functional as F
 
 _side = {}
 _pending = False
+_grad_ready_callbacks = []  # called as cb(param) right after a side-stream accumulation has been queued
+
+
+def register_grad_ready_callback(cb):
+    _grad_ready_callbacks.append(cb)
+
+
+def clear_grad_ready_callbacks():
+    _grad_ready_callbacks.clear()
+
+
+def side_streams():
+    return list(_side.values())
 
 
 def side_stream(device) -> torch.cuda.Stream:
@@ -33,6 +46,8 @@ def _accumulate(param, value):
     if param.grad is None:
         param.grad = torch.zeros_like(param)
     param.grad.add_(value.to(param.grad.dtype))
+    for cb in _grad_ready_callbacks:
+        cb(param)
 
 
 class _LinearOverlapped(torch.autograd.Function):
