@@ -263,9 +263,15 @@ def main():
             if "lstm_bwd" in summ:
                 _, ms, launches, nbytes = summ["lstm_bwd"]
                 achieved = nbytes / (ms * 1e-3) / 1e9
+                traffic = None  # PMC counters need their own rocprofv3 passes: read the committed measurement
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                    traffic = pmc["lstm_bwd_step_mfma"]["traffic_bytes_per_launch"]
+                except Exception:
+                    pass
                 out["roofline"] = {"kernel": "lstm_bwd_step_mfma (one backward timestep of all pipelined LSTM layers per launch)",
                                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                    "avg_launch_us": ms * 1e3 / launches, "launches": launches,
                                    "algorithmic_bytes_per_launch": nbytes / launches}
             if "loss_bwd" in summ:

@@ -1,0 +1,88 @@
+"""Size-independent properties at the BASELINE sizes (base-85M: H = 1024, V = 8704, B = 32, LibriSpeech-like
+lattices) where the CPU oracle would take minutes: flow conservation of the loss gradient, alpha/beta
+agreement, pack == no-pack, state-passing equivalence of the MFMA LSTM and schedule invariance of the layer
+pipeline."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _lattice(B=32, seed=0):
+    rng = np.random.default_rng(seed)
+    dur = np.clip(rng.normal(6.0, 2.0, size=B), 1.0, 9.0)
+    f_len = np.ceil(np.ceil(dur * 100 / 3) / 2).astype(np.int32)
+    y_len = np.maximum(1, np.round(3.3 * dur)).astype(np.int32)
+    return f_len, y_len
+
+
+def test_transducer_loss_properties_at_base_vocab():
+    from caiman_asr_amd.rnnt_ext.transducer.loss import TransducerLoss
+
+    V, blank = 8704, 8703
+    f_len, y_len = _lattice()
+    B, U = len(f_len), int(y_len.max())
+    g = torch.Generator(device=DEV).manual_seed(1)
+    label = torch.randint(0, blank, (B, U), device=DEV, dtype=torch.int32, generator=g)
+    bo = torch.tensor(np.cumsum(f_len.astype(np.int64) * (y_len + 1)), device=DEV)
+    rows = int(bo[-1])
+    x = (torch.randn(rows, V, device=DEV, generator=g) * 2).to(torch.bfloat16).requires_grad_(True)
+    fl, yl = torch.tensor(f_len, device=DEV), torch.tensor(y_len, device=DEV)
+    dbg = []
+    loss = TransducerLoss(packed_input=True)(x, label, fl, yl, blank, batch_offset=bo, max_f_len=int(f_len.max()),
+                                             debug_list=dbg, delay_penalty=0.01)
+    loss.sum().backward()
+    alpha, beta = dbg
+    assert torch.isfinite(loss).all() and (loss > 0).all()
+    # (1) flow conservation: for every lattice cell the gradient sums to zero over the vocabulary
+    rs = x.grad.float().sum(-1)
+    assert rs.abs().max().item() < 3e-2  # bf16 rounding of 8704 terms of magnitude <= 1
+    # occupancy: sum of the positive parts per utterance along any anti-diagonal is <= 1; total mass sanity:
+    # (2) alpha / beta agreement: alpha(T-1,U) + null(T-1,U) == beta(0,0) == -loss
+    denom = torch.logsumexp(x.detach().float(), -1)
+    off = 0
+    for b in range(B):
+        T, U1 = int(f_len[b]), int(y_len[b]) + 1
+        last = off + (T - 1) * U1 + U1 - 1
+        null = x.detach()[last, blank].float() - denom[last]
+        assert torch.allclose(alpha[b, T - 1, U1 - 1] + null, -loss[b], rtol=2e-4, atol=2e-3)
+        assert torch.allclose(beta[b, 0, 0], -loss[b])
+        off += T * U1
+    # (3) pack == no-pack on the same logits (padded copy of a few utterances)
+    sel = [0, 5, 17]
+    Tm, Um = int(f_len[sel].max()), int(y_len[sel].max())
+    xp = torch.zeros(len(sel), Tm, Um + 1, V, device=DEV, dtype=torch.bfloat16)
+    starts = np.concatenate([[0], bo.cpu().numpy()])
+    for i, b in enumerate(sel):
+        T, U1 = int(f_len[b]), int(y_len[b]) + 1
+        xp[i, :T, :U1] = x.detach()[starts[b]:starts[b] + T * U1].view(T, U1, V)
+    lp = TransducerLoss()(xp, label[sel][:, :Um].contiguous(), fl[sel], yl[sel], blank, delay_penalty=0.01)
+    # delay penalty depends on T only; labels beyond y_len are ignored
+    assert torch.allclose(lp, loss.detach()[sel], rtol=1e-5)
+
+
+def test_mfma_lstm_state_passing_and_schedule_invariance_at_base_width():
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    torch.manual_seed(0)
+    H, L, B, T = 1024, 6, 32, 70
+    m = CustomLSTM(2048, H, L, device=DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(0.5)
+    x = torch.randn(T, B, 2048, device=DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full, (hf, cf), (ah, ac) = m(x)
+        a, sa, _ = m(x[:33])
+        b, (hb, cb), _ = m(x[33:], sa)
+        m.pipeline_layers = False
+        ref, (hr, cr), _ = m(x)
+    # concat(A, B) == A then B | state  (training/tests/rnnt/test_model.py:107-296); the carried state is
+    # rounded to the input dtype (fp32 here) exactly like the hand-over inside one call is rounded to bf16
+    assert torch.allclose(torch.cat([a, b]).float(), full.float(), atol=2e-2)
+    assert torch.allclose(hb.float(), hf.float(), atol=2e-2) and torch.allclose(cb.float(), cf.float(), atol=4e-2)
+    # the layer pipeline only re-orders launches: bit-identical to the layer-by-layer schedule
+    assert torch.equal(ref, full) and torch.equal(hr, hf) and torch.equal(cr, cf)
+    assert ah.shape == (L, T, B, H) and torch.equal(ah[-1], full)
