@@ -143,6 +143,7 @@ def main():
     model = RNNT(n_classes=N_CLASSES, **BASE_RNNT).to(dev)
     model.train()
     model.overlap_weight_grads = not args.no_overlap
+    model.parallel_prediction = not args.no_overlap
     from caiman_asr_amd.rnnt_ext.custom_lstm import stack as lstm_stack
 
     lstm_stack.OVERLAP_WEIGHT_GRADS = not args.no_overlap

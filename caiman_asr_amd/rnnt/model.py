@@ -59,6 +59,9 @@ class RNNT(nn.Module):
         # opt-in: joint_fc's weight gradient runs on a side stream (train_utils/overlap.py); the training
         # loop must call overlap.wait_all() before it reads the gradients
         self.overlap_weight_grads = False
+        # opt-in: prediction network on a second stream, concurrent with the encoder
+        self.parallel_prediction = False
+        self._pred_stream = None
 
         common = dict(forget_gate_bias=forget_gate_bias, custom_lstm=custom_lstm, quantize=quantize,
                       hidden_hidden_bias_scale=hidden_hidden_bias_scale, weights_init_scale=weights_init_scale,
@@ -97,8 +100,35 @@ class RNNT(nn.Module):
     # ---- forward pieces -------------------------------------------------------
     def enc_pred(self, x, x_lens, y, y_lens, pred_net_state: Optional[PredNetState] = None,
                  enc_state: Optional[EncoderState] = None):
-        return self.enc_pred_static(x, x_lens, y, y_lens, self.encode, self.predict,
-                                    pred_net_state=pred_net_state, enc_state=enc_state)
+        if not (self.parallel_prediction and x.is_cuda):
+            return self.enc_pred_static(x, x_lens, y, y_lens, self.encode, self.predict,
+                                        pred_net_state=pred_net_state, enc_state=enc_state)
+        # same wiring as enc_pred_static, with the (short) prediction network enqueued first on its own stream
+        y = label_collate(y)
+        g, _, all_pred_hid = self._predict_on_side_stream(
+            y, pred_state=(pred_net_state.next_to_last_pred_state if pred_net_state else None), add_sos=True,
+            special_sos=pred_net_state.last_token if pred_net_state else None)
+        f, x_lens, new_enc_state = self.encode(x, x_lens, enc_state=enc_state)
+        torch.cuda.current_stream().wait_stream(self._pred_stream)
+        g_lens = y_lens + 1
+        new_pred = get_pred_net_state(y, all_pred_hid, y_lens, g_lens)
+        rnnt_state = None
+        if new_enc_state is not None and new_pred is not None:
+            rnnt_state = RNNTState(enc_state=new_enc_state, pred_net_state=new_pred)
+        return (f, x_lens), (g, g_lens), rnnt_state
+
+    def _predict_on_side_stream(self, *args, **kwargs):
+        """The prediction network does not depend on the encoder: run it (forward, and through autograd its
+        backward) on a second HIP stream so its latency-bound LSTM steps overlap the encoder's."""
+        if getattr(self, "_pred_stream", None) is None:
+            self._pred_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._pred_stream.wait_stream(main)
+        with torch.cuda.stream(self._pred_stream):
+            g, hid, all_hid = self.predict(*args, **kwargs)
+        for t in (g, *hid, *(all_hid or ())):
+            t.record_stream(main)
+        return g, hid, all_hid
 
     @staticmethod
     def enc_pred_static(x, x_lens, y, y_lens, encode, predict, pred_net_state: Optional[PredNetState] = None,

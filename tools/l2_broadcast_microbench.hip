@@ -58,6 +58,9 @@ int main() {
   };
   timeit("256 blocks read the SAME 256 KB, never written", [&](int) { hipLaunchKernelGGL(reader, dim3(256), dim3(1024), 0, 0, buf, n16, 0, sink); }, 300, 1);
   timeit("256 blocks read UNIQUE 256 KB each (64 MB total)", [&](int) { hipLaunchKernelGGL(reader, dim3(256), dim3(1024), 0, 0, buf, n16, 1, sink); }, 300, 1);
+  timeit("256 blocks read UNIQUE 64 KB each (16 MB total, fits the 8 L2s)", [&](int) { hipLaunchKernelGGL(reader, dim3(256), dim3(1024), 0, 0, buf, n16 / 4, 1, sink); }, 300, 1);
+  timeit("256 blocks read UNIQUE 32 KB each (8 MB total)", [&](int) { hipLaunchKernelGGL(reader, dim3(256), dim3(1024), 0, 0, buf, n16 / 8, 1, sink); }, 300, 1);
+  timeit("256 blocks read UNIQUE 128 KB each (32 MB total)", [&](int) { hipLaunchKernelGGL(reader, dim3(256), dim3(1024), 0, 0, buf, n16 / 2, 1, sink); }, 300, 1);
   timeit("64 blocks read the SAME 256 KB", [&](int) { hipLaunchKernelGGL(reader, dim3(64), dim3(1024), 0, 0, buf, n16, 0, sink); }, 300, 1);
   timeit("8 blocks read the SAME 256 KB", [&](int) { hipLaunchKernelGGL(reader, dim3(8), dim3(1024), 0, 0, buf, n16, 0, sink); }, 300, 1);
   timeit("256 blocks read the SAME 64 KB", [&](int) { hipLaunchKernelGGL(reader, dim3(256), dim3(1024), 0, 0, buf, n16 / 4, 0, sink); }, 300, 1);
