@@ -282,23 +282,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int ste
   const T* Abase = h_in + ((int64_t)mt * nk * 32 + r) * 32 + 8 * kq;           // + s*1024 (+512: rows 16..31)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   if constexpr (NK > 0) {
-    frag bf[NK], a0[NK], a1[NK];
+    // NK fragments of each operand are in flight at a time; wider layers take several such batches
+    for (int i0 = 0; 4 * i0 < nk; i0 += NK) {
+      frag bf[NK], a0[NK], a1[NK];
 #pragma unroll
-    for (int i = 0; i < NK; ++i) {
-      const int s = wave + 4 * i;
-      const int sc = s < nk ? s : 0;  // NK*4 may exceed nk: clamp the address, zero the product below
-      bf[i] = *reinterpret_cast<const frag*>(Bbase + (int64_t)sc * 512);
-      a0[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024);
-      a1[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024 + 512);
-      if (s >= nk) {
+      for (int i = 0; i < NK; ++i) {
+        const int s = wave + 4 * (i0 + i);
+        const int sc = s < nk ? s : 0;  // past the end: clamp the address, zero the product below
+        bf[i] = *reinterpret_cast<const frag*>(Bbase + (int64_t)sc * 512);
+        a0[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024);
+        a1[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024 + 512);
+        if (s >= nk) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) bf[i][q] = static_cast<T>(0.f);
+          for (int q = 0; q < 8; ++q) bf[i][q] = static_cast<T>(0.f);
+        }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < NK; ++i) {
-      acc0 = mfma16(a0[i], bf[i], acc0);
-      acc1 = mfma16(a1[i], bf[i], acc1);
+      for (int i = 0; i < NK; ++i) {
+        acc0 = mfma16(a0[i], bf[i], acc0);
+        acc1 = mfma16(a1[i], bf[i], acc1);
+      }
     }
   } else {
     for (int s = wave; s < nk; s += 4) {
@@ -397,23 +400,25 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int st
     const T* Abase = dG_in + ((int64_t)mt * nk4 * 32 + r) * 32 + 8 * kq;           // + s*1024 (+512)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (NK > 0) {
-      frag bf[NK], a0[NK], a1[NK];
+      for (int i0 = 0; 16 * i0 < nk4; i0 += NK) {
+        frag bf[NK], a0[NK], a1[NK];
 #pragma unroll
-      for (int i = 0; i < NK; ++i) {
-        const int s = wave + 16 * i;
-        const int sc = s < nk4 ? s : 0;
-        bf[i] = *reinterpret_cast<const frag*>(Bbase + (int64_t)sc * 512);
-        a0[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024);
-        a1[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024 + 512);
-        if (s >= nk4) {
+        for (int i = 0; i < NK; ++i) {
+          const int s = wave + 16 * (i0 + i);
+          const int sc = s < nk4 ? s : 0;
+          bf[i] = *reinterpret_cast<const frag*>(Bbase + (int64_t)sc * 512);
+          a0[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024);
+          a1[i] = *reinterpret_cast<const frag*>(Abase + (int64_t)sc * 1024 + 512);
+          if (s >= nk4) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) bf[i][q] = static_cast<T>(0.f);
+            for (int q = 0; q < 8; ++q) bf[i][q] = static_cast<T>(0.f);
+          }
         }
-      }
 #pragma unroll
-      for (int i = 0; i < NK; ++i) {
-        acc0 = mfma16(a0[i], bf[i], acc0);
-        acc1 = mfma16(a1[i], bf[i], acc1);
+        for (int i = 0; i < NK; ++i) {
+          acc0 = mfma16(a0[i], bf[i], acc0);
+          acc1 = mfma16(a1[i], bf[i], acc1);
+        }
       }
     } else {
       for (int s = wave; s < nk4; s += 16) {
@@ -467,19 +472,26 @@ constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_
 
 inline int64_t pad32(int64_t b) { return (b + 31) / 32 * 32; }
 
+// operand fragments kept in flight per wave: the whole per-wave K range when it is small (base: 8),
+// otherwise the largest batch that divides it evenly (large config, H = 1536: 12 k-steps -> 2 x 6)
+inline int pick_batch(int nkw) {
+  if (nkw <= 8) return (nkw == 1 || nkw == 2 || nkw == 4 || nkw == 6 || nkw == 8) ? nkw : (nkw == 3 ? 4 : 8);
+  for (int b : {8, 6, 4}) if (nkw % b == 0) return b;
+  return 8;  // uneven tail: the clamp-and-zero path covers it
+}
+
 template <typename T, bool HARD, bool IL>
 int launch_fwd_waves(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s) {
   const int nkw = (int)(((H >> 5) + 3) / 4);  // k-steps per wave
   const dim3 grid((unsigned)(H / 4), (unsigned)((B + 31) / 32), (unsigned)n_slots);
   for (int i = 0; i < n_launches; ++i) {
 #define CAIMAN_FWD(NKV) hipLaunchKernelGGL((lstm_fwd_step_mfma<T, HARD, NKV, IL>), grid, dim3(256), 0, s, w, i, (int)B, (int)H)
-    switch (nkw) {
+    switch (pick_batch(nkw)) {
       case 1: CAIMAN_FWD(1); break;
       case 2: CAIMAN_FWD(2); break;
       case 4: CAIMAN_FWD(4); break;
       case 6: CAIMAN_FWD(6); break;
       case 8: CAIMAN_FWD(8); break;
-      case 12: CAIMAN_FWD(12); break;
       default: CAIMAN_FWD(0); break;
     }
 #undef CAIMAN_FWD
@@ -493,7 +505,7 @@ int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t 
   const dim3 grid((unsigned)(H / 16), (unsigned)((B + 31) / 32), (unsigned)n_slots);
   for (int i = 0; i < n_launches; ++i) {
 #define CAIMAN_BWD(NKV) hipLaunchKernelGGL((lstm_bwd_step_mfma<T, HARD, NKV, IL>), grid, dim3(1024), 0, s, w, i, (int)B, (int)H)
-    switch (nkw) {
+    switch (pick_batch(nkw)) {
       case 1: CAIMAN_BWD(1); break;
       case 2: CAIMAN_BWD(2); break;
       case 4: CAIMAN_BWD(4); break;

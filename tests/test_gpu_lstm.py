@@ -55,7 +55,7 @@ def test_generic_kernels_match_oracle(T, B, H, dtype, hard):
     assert np.allclose(dG.double().cpu().numpy(), odG, atol=tol * 10)
 
 
-@pytest.mark.parametrize("T,B,H", [(6, 32, 64), (9, 5, 128), (4, 40, 256), (3, 70, 512)])
+@pytest.mark.parametrize("T,B,H", [(6, 32, 64), (9, 5, 128), (4, 40, 256), (3, 70, 512), (3, 8, 1536), (3, 33, 96), (2, 4, 224)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hard", [False, True])
 def test_mfma_kernels_match_oracle(T, B, H, dtype, hard):
