@@ -39,6 +39,9 @@ BASE_RNNT = dict(  # training/configs/base-8703sp.yaml:73-94
     joint_apex_transducer="pack", joint_apex_relu_dropout=True, forget_gate_bias=1.0, custom_lstm=True,
     quantize=False, enc_rw_dropout=0.0, pred_rw_dropout=0.0)
 N_CLASSES = 8704  # 8703 sentencepieces + blank
+# training/configs/large-17407sp.yaml: the deltas of the 196 M model (BASELINE.json configs[3])
+LARGE_RNNT = dict(BASE_RNNT, enc_n_hid=1536, pred_n_hid=768, joint_n_hid=1024, joint_net_lr_factor=0.243)
+LARGE_N_CLASSES = 17408
 
 
 def make_batches(n_batches, batch_size, seed, n_mels=80):
@@ -104,6 +107,8 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--model", choices=["base", "large"], default="base",
+                    help="base = the headline config (BASELINE configs[1]); large = the 196 M model of configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient GEMMs on the main stream")
@@ -140,7 +145,12 @@ def main():
     _lib.lib()  # fail loudly if the HIP library is missing
 
     torch.manual_seed(1234)  # identical initial weights on every rank (then broadcast anyway)
-    model = RNNT(n_classes=N_CLASSES, **BASE_RNNT).to(dev)
+    global N_CLASSES
+    rnnt_cfg = BASE_RNNT
+    if args.model == "large":
+        rnnt_cfg, N_CLASSES = LARGE_RNNT, LARGE_N_CLASSES
+        args.no_cpu_baseline = True  # the CPU sample is defined on the base config
+    model = RNNT(n_classes=N_CLASSES, **rnnt_cfg).to(dev)
     model.train()
     model.overlap_weight_grads = not args.no_overlap
     model.parallel_prediction = not args.no_overlap
@@ -247,8 +257,9 @@ def main():
             "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "base-85M RNN-T bf16 training, LibriSpeech-960 shapes, batch 32 per GPU "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": ("base-85M RNN-T bf16 training, LibriSpeech-960 shapes, batch 32 per GPU "
+                                    "(BASELINE.json configs[1])") if args.model == "base" else
+                                   "large-196M RNN-T bf16 training + on-GPU SpecAugment (BASELINE.json configs[3] shapes)",
                        "global_batch": args.batch * world, "utterance_seconds": "clip(N(12.3,3.8),1,16.7)",
                        "parallelism": f"dp{world}", "final_loss": loss_val,
                        "audio_seconds_per_step": audio_total / args.steps},
