@@ -99,6 +99,26 @@ class FusedLAMB(torch.optim.Optimizer):
         assert self.flat_ema is not None
         return {p: self.flat_ema[o:o + p.numel()].view(p.shape) for p, o in zip(self._params, self._offsets)}
 
+    # ---- checkpointing: the arenas are the state ------------------------------------------------------
+    def state_dict(self):
+        return {"flat_m": self.flat_m.detach().cpu(), "flat_v": self.flat_v.detach().cpu(),
+                "flat_ema": None if self.flat_ema is None else self.flat_ema.detach().cpu(),
+                "step": int(self._step.item()),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "layout": [(tuple(p.shape), o) for p, o in zip(self._params, self._offsets)]}
+
+    def load_state_dict(self, sd):
+        layout = [(tuple(p.shape), o) for p, o in zip(self._params, self._offsets)]
+        if [tuple(x) for x in map(lambda t: (tuple(t[0]), t[1]), sd["layout"])] != layout:
+            raise RuntimeError("optimizer checkpoint does not match this model's parameter arena")
+        self.flat_m.copy_(sd["flat_m"])
+        self.flat_v.copy_(sd["flat_v"])
+        if self.flat_ema is not None and sd.get("flat_ema") is not None:
+            self.flat_ema.copy_(sd["flat_ema"])
+        self._step.fill_(int(sd["step"]))
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update(saved)
+
     @torch.no_grad()
     def step(self, closure=None, inv_grad_scale: float = 1.0, zero_grad: bool = False):
         import ctypes

@@ -195,6 +195,12 @@ def main():
     assert sr == 16000 and bps == 16 and pcm.shape[1] == 1 and np.array_equal(gold[0], gold[1])
     np.savez_compressed(os.path.join(OUT, "frontend_ref.npz"), pcm=pcm[:, 0].astype(np.int16), sample_rate=sr,
                         logmel_norm=gold[0].astype(np.float32), window_size=0.02, window_stride=0.01, n_fft=512)
+    # the reference's hardware-checkpoint fixture holds a 1 538-parameter RNN-T written by the reference itself:
+    # its state_dict (names / shapes / values) + rnnt config pin the checkpoint schema (data only)
+    hw = torch.load(f"{td}/hardware_ckpt.pt", weights_only=True)
+    np.savez_compressed(os.path.join(OUT, "ref_ckpt_mini.npz"), rnnt_config=json.dumps(hw["rnnt_config"]["rnnt"]),
+                        epoch=hw["epoch"], step=hw["step"], best_wer=hw["best_wer"], version=hw["version"],
+                        **{"sd." + k: v.numpy() for k, v in hw["state_dict"].items()})
     for name in ("melmeans", "melvars"):
         np.save(os.path.join(OUT, f"{name}.npy"), torch.load(f"{td}/{name}.pt").numpy())
     print("golden vectors written to", OUT)

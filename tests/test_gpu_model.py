@@ -305,3 +305,38 @@ def test_parallel_prediction_stream_gives_identical_results():
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])
     for n in res[0][2]:
         assert torch.equal(res[0][2][n], res[1][2][n]), n
+
+
+def test_optimizer_state_and_ema_checkpoint_roundtrip(tmp_path):
+    from argparse import Namespace
+
+    from caiman_asr_amd.export.checkpointer import Checkpointer, ema_state_dict
+    from caiman_asr_amd.train_utils.optimizer import build_optimizer
+
+    g, sd, cfg, m = build("tiny")
+    args = Namespace(lr=4e-3, weight_decay=1e-2, beta1=0.9, beta2=0.999, clip_norm=1.0, ema=0.9)
+    opt = build_optimizer(args, m)
+    for p in m.parameters():
+        p.grad.normal_()
+    opt.step()
+    ema_sd = ema_state_dict(m, opt)
+    assert list(ema_sd) == list(m.state_dict())
+    w, e = m.joint_enc.weight, ema_sd["joint_enc.weight"]
+    w0 = torch.tensor(sd["joint_enc.weight"], device=DEV)
+    assert torch.allclose(e, 0.9 * w0 + 0.1 * w, atol=1e-6) and not torch.equal(e, w)
+    ck = Checkpointer(str(tmp_path), "RNN-T")
+    ck.save(m, ema_sd, opt, 1, 7, 0.5, {}, 1.0)
+    g2, sd2, cfg2, m2 = build("tiny")
+    opt2 = build_optimizer(args, m2)
+    meta = {"best_wer": 1.0, "step": 0}
+    ck.load(ck.last_checkpoint(), m2, None, opt2, meta)
+    assert meta["step"] == 7 and int(opt2._step.item()) == 1
+    assert torch.equal(opt2.flat_m, opt.flat_m) and torch.equal(opt2.flat_v, opt.flat_v)
+    assert torch.equal(opt2.flat_ema, opt.flat_ema) and torch.equal(opt2.flat_p, opt.flat_p)
+    # identical next step after resume
+    for p, q in zip(m.parameters(), m2.parameters()):
+        p.grad.fill_(0.01)
+        q.grad.fill_(0.01)
+    opt.step()
+    opt2.step()
+    assert torch.equal(opt2.flat_p, opt.flat_p)
