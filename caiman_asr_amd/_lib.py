@@ -72,7 +72,8 @@ _lib = None
 class FwdSlot(ctypes.Structure):
     _fields_ = [("weights_tiled", ctypes.c_void_p), ("gates", ctypes.c_void_p), ("c", ctypes.c_void_p),
                 ("y", ctypes.c_void_p), ("ring", ctypes.c_void_p), ("parity", ctypes.c_int32),
-                ("nsteps", ctypes.c_int32)]
+                ("nsteps", ctypes.c_int32), ("y_masked", ctypes.c_void_p), ("drop_counter", ctypes.c_uint64),
+                ("drop_p", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
 
 class BwdSlot(ctypes.Structure):
@@ -80,7 +81,7 @@ class BwdSlot(ctypes.Structure):
                 ("delta", ctypes.c_void_p), ("delta_stride_t", ctypes.c_int64), ("delta_stride_b", ctypes.c_int64),
                 ("dG", ctypes.c_void_p), ("ring", ctypes.c_void_p), ("dC", ctypes.c_void_p),
                 ("parity", ctypes.c_int32), ("nsteps", ctypes.c_int32), ("has_next", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("drop_p", ctypes.c_float), ("drop_counter", ctypes.c_uint64)]
 
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
@@ -103,8 +104,9 @@ _SIGS = {
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_lstm_workspace_elems": ([I64, I64, I32], ctypes.c_int64),
     "caiman_lstm_prepare": ([P, P, P, P, P, I64, I64, I32, I32, I32, P], ctypes.c_int),
-    "caiman_lstm_wave_fwd": ([P, I32, I32, I64, I64, I32, I32, I32, P], ctypes.c_int),
-    "caiman_lstm_wave_bwd": ([P, I32, I32, I64, I64, I32, I32, I32, P], ctypes.c_int),
+    "caiman_lstm_wave_fwd": ([P, I32, I32, I64, I64, I32, I32, I32, ctypes.c_uint64, P], ctypes.c_int),
+    "caiman_lstm_wave_bwd": ([P, I32, I32, I64, I64, I32, I32, I32, ctypes.c_uint64, P], ctypes.c_int),
+    "caiman_lstm_dropout_mask": ([P, I64, ctypes.c_uint64, ctypes.c_uint64, F32, I32, P], ctypes.c_int),
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),

@@ -198,6 +198,18 @@ __device__ __forceinline__ int64_t tiled_index(int b, int k, int nk) {
   return (((int64_t)(b >> 5) * nk + (k >> 5)) * 32 + (b & 31)) * 32 + (k & 31);
 }
 
+// Inter-layer dropout without mask tensors: keep(seed, element counter) is a pure function, evaluated in the
+// forward epilogue (to emit the masked copy the next layer's input GEMM reads) and again in the backward
+// epilogue of the layer below (to mask the incoming gradient).  Same splitmix64 counter hash as csrc/joint.hip.
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : inv_keep;
+}
+
 // A launch ("wave") can advance SEVERAL independent recurrences at once: blockIdx.z selects a slot
 // (one LSTM layer working on its own timestep).  That is how a stack of layers is pipelined: layer l
 // runs a chunk of timesteps behind layer l-1, so the number of dependent kernel boundaries is
@@ -213,6 +225,12 @@ struct FwdSlots {
   T* hring[kMaxSlots];  // 2 x pad32(B) x H tiled
   int parity[kMaxSlots];  // ring half that holds h of the slot's first step input
   int nsteps[kMaxSlots];
+  // optional masked copy of the output for the layer above: ymask row of the first step OUTPUT (NULL: none),
+  // element counter of that row's first element, dropout probability
+  T* ymask[kMaxSlots];
+  uint64_t drop_base[kMaxSlots];
+  float drop_p[kMaxSlots];
+  uint64_t seed;
 };
 
 template <typename T>
@@ -228,6 +246,11 @@ struct BwdSlots {
   int parity[kMaxSlots];      // t_hi & 1
   int nsteps[kMaxSlots];
   int has_in0[kMaxSlots];     // 0 when t_hi is the last timestep of the sequence (no dG[t+1])
+  // delta is the UNMASKED gradient w.r.t. the dropped-out copy of this layer's output: multiply by the same
+  // keep/scale the forward applied (drop_p == 0: delta is used as is); counter of row t_hi's first element
+  uint64_t drop_base[kMaxSlots];
+  float drop_p[kMaxSlots];
+  uint64_t seed;
 };
 
 // ---- forward step: grid (H/4, ceil(B/32), slots), 256 threads = 4 waves -----------------------
@@ -332,6 +355,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int ste
   const T yv = static_cast<T>(o * Act<float, HARD>::tanhv(c));
   h_out[tiled_index(be, ne, nk)] = yv;  // what the next step reads
   y1[(int64_t)be * H + ne] = yv;
+  if (w.ymask[slot]) {
+    const float pd = w.drop_p[slot];
+    const uint64_t ctr = w.drop_base[slot] + (uint64_t)step * (uint64_t)so + (uint64_t)be * H + ne;
+    w.ymask[slot][so * step + (int64_t)be * H + ne] =
+        static_cast<T>(static_cast<float>(yv) * drop_scale(w.seed, ctr, pd, 1.f / (1.f - pd)));
+  }
   c1[(int64_t)be * H + ne] = static_cast<T>(c);
   if constexpr (IL) {
     g4 v;
@@ -379,6 +408,11 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int st
   float dy = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go_ = 0.f, cp = 0.f, cc = 0.f, dcf = 0.f;
   if (ep) {
     dy = static_cast<float>(delta[(int64_t)be * d_sb + ne]);
+    if (w.drop_p[slot] > 0.f) {
+      const float pd = w.drop_p[slot];
+      const uint64_t ctr = w.drop_base[slot] - (uint64_t)step * (uint64_t)so + (uint64_t)be * H + ne;
+      dy *= drop_scale(w.seed, ctr, pd, 1.f / (1.f - pd));
+    }
     if constexpr (IL) {
       const g4 v = *reinterpret_cast<const g4*>(g + gb);
       gi = static_cast<float>(v[0]); gf = static_cast<float>(v[1]);
@@ -601,6 +635,29 @@ extern "C" int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backwar
   return 4 * H * H + 2 * bp * (backward ? 4 * H : H);
 }
 
+namespace caiman { namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_mask_kernel(T* __restrict__ out, int64_t n, uint64_t seed, uint64_t base, float p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = static_cast<T>(drop_scale(seed, base + (uint64_t)i, p, 1.f / (1.f - p)));
+}
+} }  // namespace
+
+// keep/scale factors the LSTM kernels apply for element counters base .. base+n-1 (tests, debugging)
+extern "C" int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base, float p, int dtype,
+                                        caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(out && n >= 0 && p >= 0.f && p < 1.f, "lstm_dropout_mask: bad arguments");
+  CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16 || dtype == CAIMAN_F32, "lstm_dropout_mask: f16 / bf16 / f32");
+  if (n == 0) return CAIMAN_OK;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == CAIMAN_BF16) hipLaunchKernelGGL((dropout_mask_kernel<bf16_t>), grid, dim3(256), 0, s, (bf16_t*)out, n, seed, base, p);
+  else if (dtype == CAIMAN_F16) hipLaunchKernelGGL((dropout_mask_kernel<f16_t>), grid, dim3(256), 0, s, (f16_t*)out, n, seed, base, p);
+  else hipLaunchKernelGGL((dropout_mask_kernel<float>), grid, dim3(256), 0, s, (float*)out, n, seed, base, p);
+  return check_launch("caiman_lstm_dropout_mask");
+}
+
 // ---- multi-layer ("wave") interface -----------------------------------------------------------------
 extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
                                    int64_t B, int64_t H, int dtype, int backward, int gate_layout,
@@ -618,7 +675,8 @@ extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_
 }
 
 extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches, int64_t B,
-                                    int64_t H, int dtype, int hard, int gate_layout, caiman_stream_t stream) {
+                                    int64_t H, int dtype, int hard, int gate_layout, uint64_t seed,
+                                    caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(slots && n_slots >= 1 && n_slots <= kMaxSlots, "lstm_wave_fwd: 1..%d slots", kMaxSlots);
   CAIMAN_CHECK(B >= 1 && B <= 32 * 65535 && H >= 32 && H % 32 == 0, "lstm_wave_fwd: bad extents");
@@ -636,7 +694,10 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
       w.Rtile[i] = (const T*)slots[i].weights_tiled; w.g[i] = (T*)slots[i].gates; w.c[i] = (T*)slots[i].c;
       w.y[i] = (T*)slots[i].y; w.hring[i] = (T*)slots[i].ring; w.parity[i] = slots[i].parity & 1;
       w.nsteps[i] = slots[i].nsteps;
+      w.ymask[i] = (T*)slots[i].y_masked; w.drop_base[i] = slots[i].drop_counter; w.drop_p[i] = slots[i].drop_p;
+      CAIMAN_CHECK(slots[i].drop_p >= 0.f && slots[i].drop_p < 1.f, "lstm_wave_fwd: dropout p must be in [0,1)");
     }
+    w.seed = seed;
     if (gate_layout)
       return hard ? launch_fwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
                   : launch_fwd_waves<T, false, true>(w, n_slots, n_launches, B, H, s);
@@ -647,7 +708,8 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
 }
 
 extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n_launches, int64_t B,
-                                    int64_t H, int dtype, int hard, int gate_layout, caiman_stream_t stream) {
+                                    int64_t H, int dtype, int hard, int gate_layout, uint64_t seed,
+                                    caiman_stream_t stream) {
   using namespace caiman;
   CAIMAN_CHECK(slots && n_slots >= 1 && n_slots <= kMaxSlots, "lstm_wave_bwd: 1..%d slots", kMaxSlots);
   CAIMAN_CHECK(B >= 1 && B <= 32 * 65535 && H >= 32 && H % 32 == 0, "lstm_wave_bwd: bad extents");
@@ -666,7 +728,10 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
       w.delta[i] = (const T*)slots[i].delta; w.d_st[i] = slots[i].delta_stride_t; w.d_sb[i] = slots[i].delta_stride_b;
       w.dG[i] = (T*)slots[i].dG; w.dring[i] = (T*)slots[i].ring; w.dC[i] = (float*)slots[i].dC;
       w.parity[i] = slots[i].parity & 1; w.nsteps[i] = slots[i].nsteps; w.has_in0[i] = slots[i].has_next ? 1 : 0;
+      w.drop_base[i] = slots[i].drop_counter; w.drop_p[i] = slots[i].drop_p;
+      CAIMAN_CHECK(slots[i].drop_p >= 0.f && slots[i].drop_p < 1.f, "lstm_wave_bwd: dropout p must be in [0,1)");
     }
+    w.seed = seed;
     if (gate_layout)
       return hard ? launch_bwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
                   : launch_bwd_waves<T, false, true>(w, n_slots, n_launches, B, H, s);

@@ -69,7 +69,11 @@ def _pad32(b):
 
 class StackFunction(torch.autograd.Function):
     """forward(x [T,B,I], h0 [L,B,H], c0 [L,B,H], hard, p_drop, training, W_0, R_0, bW_0, bR_0, W_1, ...)
-    -> (y_top [T,B,H], all_h [L,T,B,H], all_c [L,T,B,H]).  Gradients flow to x and the parameters."""
+    -> (y_top [T,B,H], all_h [L,T,B,H], all_c [L,T,B,H]).  Gradients flow to x and the parameters.
+
+    Inter-layer dropout is fused into the step kernels (counter-hash mask, no mask tensors): the forward epilogue of
+    layer l also writes the masked copy that layer l+1 multiplies with W_ih, the backward epilogue of layer l masks
+    the gradient arriving from layer l+1."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -79,7 +83,6 @@ class StackFunction(torch.autograd.Function):
         T, B, _ = x.shape
         dev = x.device
         lib = _lib.lib()
-        # layer 0: every timestep's input contribution in one GEMM (autocast decides the gate dtype)
         H = Rs[0].shape[1]
         # the pipeline keeps gates / dG unit-major ([.., H, 4]): permute the ROWS of W_ih and of the biases once
         # per call (R keeps its layout: the tiling kernels absorb the permutation)
@@ -96,10 +99,9 @@ class StackFunction(torch.autograd.Function):
         Rp = [R.to(dt).contiguous() for R in Rs]
         Wp = [_perm_rows(W, H).to(dt) for W in Ws]
         bias = [_perm_rows(bWs[l] + bRs[l], H).to(dt) for l in range(L)]
-        masks: List[Optional[torch.Tensor]] = [None] * L
-        if training and p_drop > 0.0:
-            for l in range(1, L):
-                masks[l] = (torch.rand((T, B, H), device=dev) >= p_drop).to(dt) * (1.0 / (1.0 - p_drop))
+        drop = float(p_drop) if (training and p_drop > 0.0 and L > 1) else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop > 0.0 else 0
+        YM = torch.empty((L - 1, T, B, H), dtype=dt, device=dev) if drop > 0.0 else None  # masked outputs
         bp = _pad32(B)
         wt = _Scratch.get("fw", L * 4 * H * H, dt, dev).view(L, -1)
         ring = _Scratch.get("fr", L * 2 * bp * H, dt, dev).view(L, -1)
@@ -109,30 +111,33 @@ class StackFunction(torch.autograd.Function):
                                                 None, B, H, tag, 0, INTERLEAVED, st))
         CH = _chunk(L)
         n_ch = (T + CH - 1) // CH
-        es = G.element_size()
-        sb = _step_bytes(B, H, es, False)
-        if True:
-            for tau in range(n_ch + L - 1):
-                slots = []
-                for l in range(L):
-                    k = tau - l
-                    if k < 0 or k >= n_ch:
-                        continue
-                    t0, n = k * CH, min(CH, T - k * CH)
-                    if l >= 1:  # input GEMM of this layer's chunk on what layer l-1 produced last tick
-                        xin = Y[l - 1, 1 + t0:1 + t0 + n]
-                        if masks[l] is not None:
-                            xin = xin * masks[l][t0:t0 + n]
-                        torch.addmm(bias[l], xin.reshape(n * B, H), Wp[l].t(), out=G[l, t0:t0 + n].view(n * B, 4 * H))
-                    slots.append(_lib.FwdSlot(wt[l].data_ptr(), G[l, t0].data_ptr(), Cs[l, t0].data_ptr(),
-                                              Y[l, t0].data_ptr(), ring[l].data_ptr(), t0 & 1, n))
-                arr = (_lib.FwdSlot * len(slots))(*slots)
-                n_launch = max(s_.nsteps for s_ in slots)
-                with _lib.timed("lstm_fwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
-                    _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
-                                                        tag, int(hard), INTERLEAVED, st))
-        ctx.save_for_backward(x, G, Y, Cs, *Wp, *Rp, *[m for m in masks if m is not None])
-        ctx.meta = (L, T, B, H, hard, [m is not None for m in masks], x.requires_grad)
+        sb = _step_bytes(B, H, G.element_size(), False)
+        row = B * H
+        for tau in range(n_ch + L - 1):
+            slots = []
+            for l in range(L):
+                k = tau - l
+                if k < 0 or k >= n_ch:
+                    continue
+                t0, n = k * CH, min(CH, T - k * CH)
+                if l >= 1:  # input GEMM of this layer's chunk on what layer l-1 produced last tick
+                    src = YM[l - 1, t0:t0 + n] if drop > 0.0 else Y[l - 1, 1 + t0:1 + t0 + n]
+                    torch.addmm(bias[l], src.reshape(n * B, H), Wp[l].t(), out=G[l, t0:t0 + n].view(n * B, 4 * H))
+                masked = drop > 0.0 and l < L - 1
+                slots.append(_lib.FwdSlot(wt[l].data_ptr(), G[l, t0].data_ptr(), Cs[l, t0].data_ptr(),
+                                          Y[l, t0].data_ptr(), ring[l].data_ptr(), t0 & 1, n,
+                                          YM[l, t0].data_ptr() if masked else None, (l * T + t0) * row,
+                                          drop if masked else 0.0, 0))
+            arr = (_lib.FwdSlot * len(slots))(*slots)
+            n_launch = max(s_.nsteps for s_ in slots)
+            with _lib.timed("lstm_fwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
+                _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
+                                                    tag, int(hard), INTERLEAVED, seed, st))
+        saved = [x, G, Y, Cs, *Wp, *Rp]
+        if YM is not None:
+            saved.append(YM)
+        ctx.save_for_backward(*saved)
+        ctx.meta = (L, T, B, H, hard, drop, seed, x.requires_grad)
         ctx.params = params
         y_top = Y[L - 1, 1:]
         all_h, all_c = Y[:, 1:], Cs[:, 1:]
@@ -142,22 +147,32 @@ class StackFunction(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, d_top, d_allh, _d_allc):
-        L, T, B, H, hard, has_mask, need_dx = ctx.meta
+        L, T, B, H, hard, drop, seed, need_dx = ctx.meta
         saved = ctx.saved_tensors
         x, G, Y, Cs = saved[:4]
         Wp, Rp = saved[4:4 + L], saved[4 + L:4 + 2 * L]
-        mask_list = list(saved[4 + 2 * L:])
-        masks = [mask_list.pop(0) if hm else None for hm in has_mask]
+        YM = saved[4 + 2 * L] if drop > 0.0 else None
         dev, dt = G.device, G.dtype
         tag = _lib.dtype_tag(dt)
         lib = _lib.lib()
         st = _lib.stream()
+        row = B * H
         dG = torch.empty_like(G)
-        # upstream gradient of every layer's output sequence; the top one arrives from autograd, the others
-        # are produced chunk by chunk from the layer above (plus any direct gradient on all_h)
-        delta = torch.zeros((L, T, B, H), dtype=dt, device=dev) if d_allh is None else d_allh.to(dt).clone()
-        if d_top is not None:
-            delta[L - 1] += d_top.to(dt)
+        # delta[l] = gradient w.r.t. the (masked) output sequence of layer l.  Top layer: what autograd hands us;
+        # lower layers: dG_{l+1}·W_{l+1}, written chunk by chunk by the library GEMM; the dropout factor is applied
+        # inside the step kernel.  A direct gradient on all_h (random state passing never produces one, states are
+        # detached) takes the general path: materialise the factors and fold everything into delta.
+        fused_mask = d_allh is None
+        if d_top is None:
+            d_top = torch.zeros((T, B, H), dtype=dt, device=dev)
+        d_top = d_top.to(dt)
+        if d_top.stride(2) != 1:
+            d_top = d_top.contiguous()
+        delta_low = torch.empty((L - 1, T, B, H), dtype=dt, device=dev) if L > 1 else None
+        extra = None
+        if not fused_mask:
+            extra = d_allh.to(dt)
+            d_top = d_top + extra[L - 1]
         bp = _pad32(B)
         wt = _Scratch.get("bw", L * 4 * H * H, dt, dev).view(L, -1)
         ring = _Scratch.get("br", L * 2 * bp * 4 * H, dt, dev).view(L, -1)
@@ -168,39 +183,48 @@ class StackFunction(torch.autograd.Function):
         CH = _chunk(L)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), True)
-        if True:
-            for tau in range(n_ch + L - 1):
-                slots = []
-                for l in range(L - 1, -1, -1):
-                    j = tau - (L - 1 - l)  # how many chunks this layer has already finished
-                    if j < 0 or j >= n_ch:
-                        continue
-                    k = n_ch - 1 - j
-                    t0, n = k * CH, min(CH, T - k * CH)
-                    thi = t0 + n - 1
-                    if l < L - 1:  # gradient from the layer above for this chunk: dX = dG_{l+1} @ W_{l+1}
-                        dx = torch.matmul(dG[l + 1, t0:t0 + n].view(n * B, 4 * H), Wp[l + 1]).view(n, B, H)
-                        if masks[l + 1] is not None:
-                            dx = dx * masks[l + 1][t0:t0 + n]
-                        delta[l, t0:t0 + n] += dx
-                    d = delta[l]
-                    slots.append(_lib.BwdSlot(wt[l].data_ptr(), G[l, thi].data_ptr(), Cs[l, thi].data_ptr(),
-                                              d[thi].data_ptr(), d.stride(0), d.stride(1), dG[l, thi].data_ptr(),
-                                              ring[l].data_ptr(), dC[l].data_ptr(), thi & 1, n, int(thi < T - 1), 0))
-                arr = (_lib.BwdSlot * len(slots))(*slots)
-                n_launch = max(s_.nsteps for s_ in slots)
-                with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
-                    _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
-                                                        tag, int(hard), INTERLEAVED, st))
+        for tau in range(n_ch + L - 1):
+            slots = []
+            for l in range(L - 1, -1, -1):
+                j = tau - (L - 1 - l)  # how many chunks this layer has already finished
+                if j < 0 or j >= n_ch:
+                    continue
+                k = n_ch - 1 - j
+                t0, n = k * CH, min(CH, T - k * CH)
+                thi = t0 + n - 1
+                p_slot = 0.0
+                if l < L - 1:  # gradient from the layer above for this chunk: dX = dG_{l+1} @ W_{l+1}
+                    out = delta_low[l, t0:t0 + n].view(n * B, H)
+                    torch.matmul(dG[l + 1, t0:t0 + n].view(n * B, 4 * H), Wp[l + 1], out=out)
+                    if drop > 0.0:
+                        if fused_mask:
+                            p_slot = drop
+                        else:
+                            m = torch.empty((n, B, H), dtype=dt, device=dev)
+                            _lib.check(lib.caiman_lstm_dropout_mask(_lib.ptr(m), m.numel(), seed, (l * T + t0) * row,
+                                                                    drop, tag, st))
+                            delta_low[l, t0:t0 + n].mul_(m)
+                    if not fused_mask:
+                        delta_low[l, t0:t0 + n] += extra[l, t0:t0 + n]
+                    d = delta_low[l]
+                else:
+                    d = d_top
+                slots.append(_lib.BwdSlot(wt[l].data_ptr(), G[l, thi].data_ptr(), Cs[l, thi].data_ptr(),
+                                          d[thi].data_ptr(), d.stride(0), d.stride(1), dG[l, thi].data_ptr(),
+                                          ring[l].data_ptr(), dC[l].data_ptr(), thi & 1, n, int(thi < T - 1),
+                                          p_slot, (l * T + thi) * row))
+            arr = (_lib.BwdSlot * len(slots))(*slots)
+            n_launch = max(s_.nsteps for s_ in slots)
+            with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
+                _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
+                                                    tag, int(hard), INTERLEAVED, seed, st))
+
         def weight_grads(l):
             dg = dG[l].view(T * B, 4 * H)
             if l == 0:
                 xin = x.detach().flatten(0, 1).to(dt)
             else:
-                xin = Y[l - 1, 1:]
-                if masks[l] is not None:
-                    xin = xin * masks[l]
-                xin = xin.reshape(T * B, H)
+                xin = (YM[l - 1] if drop > 0.0 else Y[l - 1, 1:]).reshape(T * B, H)
             dB = _unperm_rows(dg.sum(0), H)
             return [_unperm_rows(torch.matmul(dg.t(), xin), H),
                     _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
@@ -217,7 +241,7 @@ class StackFunction(torch.autograd.Function):
                     for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], weight_grads(l)):
                         if p_.requires_grad:
                             overlap._accumulate(p_, g_)
-            for t_ in (dG, Y, x, *[m for m in masks if m is not None]):
+            for t_ in (dG, Y, x, *([YM] if YM is not None else [])):
                 t_.record_stream(side)
             overlap._pending = True
             return (dX, None, None, None, None, None, *([None] * (4 * L)))

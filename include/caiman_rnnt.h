@@ -141,15 +141,23 @@ int caiman_lstm_fused_bwd(const void* R, const void* gates, const void* c, const
  * forward slot : pointers at the slot's FIRST timestep t0 of this call: gates row t0, c / y row t0
  *   (inputs; outputs go to row t0+1 ...), parity = t0 & 1, nsteps = timesteps to run (<= n_launches).
  * backward slot: pointers at the slot's LAST timestep t_hi of this call (rows walk downwards):
- *   gates / c / delta / dG row t_hi, parity = t_hi & 1, has_next = (t_hi is not the final timestep). */
+ *   gates / c / delta / dG row t_hi, parity = t_hi & 1, has_next = (t_hi is not the final timestep).
+ * Inter-layer dropout is fused: a forward slot with y_masked != NULL also writes
+ *   y_masked[row] = y[row] * keep(seed, drop_counter + element) / (1 - drop_p)   (rows parallel to y's OUTPUT rows)
+ * which is what the layer above multiplies with W_ih; a backward slot with drop_p > 0 multiplies the incoming
+ * delta (gradient w.r.t. the masked copy) by the same factor.  keep() is a counter hash (no mask tensors);
+ * drop_counter is the counter of the first element of the slot's first output row (forward) / of row t_hi
+ * (backward); caiman_lstm_dropout_mask materialises the factors for tests. */
 typedef struct {
   const void* weights_tiled; void* gates; void* c; void* y; void* ring;
   int32_t parity; int32_t nsteps;
+  void* y_masked; uint64_t drop_counter; float drop_p; int32_t reserved;
 } caiman_lstm_fwd_slot_t;
 typedef struct {
   const void* weights_tiled; const void* gates; const void* c; const void* delta;
   int64_t delta_stride_t; int64_t delta_stride_b; void* dG; void* ring; void* dC;
-  int32_t parity; int32_t nsteps; int32_t has_next; int32_t reserved;
+  int32_t parity; int32_t nsteps; int32_t has_next; float drop_p;
+  uint64_t drop_counter;
 } caiman_lstm_bwd_slot_t;
 /* gate_layout: 0 = the reference's gates / dG layout [B, 4, H] (gate-major, lstm.cu:99-102);
  *              1 = interleaved [B, H, 4] (the 4 gates of a hidden unit adjacent): an internal layout of the
@@ -160,10 +168,12 @@ int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void
                         caiman_stream_t stream);
 int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches,
                          int64_t B, int64_t H, int dtype, int hard, int gate_layout,
-                         caiman_stream_t stream);
+                         uint64_t seed, caiman_stream_t stream);
 int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n_launches,
                          int64_t B, int64_t H, int dtype, int hard, int gate_layout,
-                         caiman_stream_t stream);
+                         uint64_t seed, caiman_stream_t stream);
+int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base, float p, int dtype,
+                             caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not

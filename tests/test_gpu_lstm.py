@@ -228,3 +228,53 @@ def test_layer_pipelined_stack_close_to_torch_lstm_and_dropout_mask_consistency(
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y_eval, _, _ = m(x)
     assert not torch.equal(y_eval, res[0][0])  # dropout really was active in training mode
+
+
+def test_fused_interlayer_dropout_matches_explicit_masks():
+    """The pipeline applies inter-layer dropout inside the step kernels (counter-hash keep factors). Rebuild the
+    same factors with caiman_lstm_dropout_mask and run the layer-by-layer path with explicit mask multiplies:
+    outputs and gradients must agree (the reference applies nn.Dropout between layers,
+    training/lib/src/rnnt_ext/custom_lstm/lstm.py:366)."""
+    import ctypes
+
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt_ext.custom_lstm import lstm as L_
+
+    T, B, I, H, L, p = 37, 6, 24, 64, 3, 0.3
+    torch.manual_seed(11)
+    m = L_.CustomLSTM(I, H, L, dropout=p, device=DEV)
+    x1 = torch.randn(T, B, I, device=DEV, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    w = torch.randn(T, B, H, device=DEV)
+
+    torch.manual_seed(123)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1, _, _ = m(x1)
+    (y1.float() * w).sum().backward()
+    g1 = [p_.grad.clone() for p_ in m.parameters()]
+    m.zero_grad()
+
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    masks = []
+    for l in range(L - 1):
+        mk = torch.empty(T, B, H, device=DEV, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().caiman_lstm_dropout_mask(_lib.ptr(mk), mk.numel(), seed, l * T * B * H, p,
+                                                       _lib.dtype_tag(torch.bfloat16), _lib.stream()))
+        masks.append(mk)
+        frac = (mk == 0).float().mean().item()
+        assert abs(frac - p) < 0.03 and torch.allclose(mk[mk != 0].float(), torch.tensor(1 / (1 - p), device=DEV), rtol=1e-2)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h = x2
+        z = torch.zeros(B, H, device=DEV)
+        for l, layer in enumerate(m.layers):
+            if l > 0:
+                h = h * masks[l - 1]
+            h, _ = layer(h, (z, z))
+    (h.float() * w).sum().backward()
+    # the kernel scales by 1/(1-p) in f32, the explicit path by its bf16 rounding: equal up to bf16 resolution
+    assert torch.allclose(y1.float(), h.float(), atol=1e-2 * h.abs().max().item())
+    assert ((y1 == 0) == (h == 0)).all()
+    assert torch.allclose(x1.grad, x2.grad, atol=3e-2 * x2.grad.abs().max().item())
+    for a, p_ in zip(g1, m.parameters()):
+        assert torch.allclose(a, p_.grad, atol=3e-2 * (p_.grad.abs().max().item() + 1e-6))
