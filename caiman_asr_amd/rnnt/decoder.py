@@ -207,6 +207,8 @@ def flatten_responses(responses: List[Dict[int, FrameResponses]]):
     for per_utt in responses:
         tk, fr, cf = [], [], []
         for t in sorted(per_utt):
+            if per_utt[t].final is None:  # beam search: frames without a newly shared prefix
+                continue
             hyp = per_utt[t].final.alternatives[0]
             tk += hyp.y_seq
             fr += hyp.timesteps

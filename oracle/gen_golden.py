@@ -33,7 +33,7 @@ def _install_stubs():
         return m
 
     def ident(*a, **k):
-        if len(a) == 1 and callable(a[0]) and not k:
+        if len(a) == 1 and not k:  # @beartype on a function, class, classmethod or staticmethod object
             return a[0]
         return lambda f: f
 
@@ -54,8 +54,18 @@ def _install_stubs():
             pass
 
     stub("apex.contrib.transducer", TransducerJoint=TransducerJoint)
-    stub("kenlm")
-    stub("cerberus")
+    class _Empty:  # placeholder type for annotations / unused validators
+        def __init__(self, *a, **k):
+            pass
+
+    stub("kenlm", State=_Empty, Model=_Empty, LanguageModel=_Empty)  # n-gram rescoring is not exercised (ngram_info=None)
+    class _AcceptAll(_Empty):  # the keyword lists written below are well-formed by construction
+        errors = {}
+
+        def validate(self, *a, **k):
+            return True
+
+    stub("cerberus", Validator=_AcceptAll)                           # keyword-list schema check
     # the compiled CUDA extensions cannot exist here; only pure-Python helpers of the modules
     # that import them (get_packing_meta_data) are used below.
     sys.path.insert(0, os.path.join(REF, "lib", "src"))
@@ -150,6 +160,70 @@ def main():
             greedy=json.dumps(dict(tokens=toks, frames=frames, confidence=confs)),
             **{"sd." + k: v for k, v in sd.items()})
         print(tag, "logits", tuple(logits.shape), "greedy", toks)
+
+    # ---- 2b. beam search (width 4, temperature 1.4, reference defaults) on the "mfma" mini model -------------
+    # The reference decoder asserts that <unk> (id 0) is never emitted, so its logit is pushed far down; the
+    # sentencepiece pieces it uses for hypothesis merging are stored so that no .model file has to travel.
+    from sentencepiece import SentencePieceProcessor as SPP
+
+    from caiman_asr_train.rnnt.beam import RNNTBeamDecoder
+
+    spm = f"{REF}/tests/test_data/librispeech29.model"
+    pieces = [SPP(model_file=spm).id_to_piece(i) for i in range(29)]
+    g = np.load(os.path.join(OUT, "rnnt_mfma.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    V = int(g["n_classes"])
+    m = RNNT(n_classes=V, **cfg).eval()
+    sd = {k[3:]: torch.tensor(g[k]) for k in g.files if k.startswith("sd.")}
+    sd["joint_net.2.bias"][0] = -30.0
+    m.load_state_dict(sd)
+    from caiman_asr_train.rnnt.eos_strategy import EOSBlank, EOSIgnore, EOSPredict
+
+    beam_cases = {
+        "default": dict(max_symbols_per_step=8),
+        "capped": dict(max_symbols_per_step=2, beam_width=3),
+        "wide": dict(beam_width=8, beam_prune_score_thresh=-1, beam_prune_topk_thresh=-1, max_symbols_per_step=4),
+        "partials": dict(return_partials=True),
+        "forced_finals": dict(final_emission_thresh=0.06, frame_width=0.06),
+        "vad": dict(eos_vad_threshold=0.12, frame_width=0.06, beam_width=2, temperature=0.7),
+        "sample_cap": dict(max_symbol_per_sample=3),
+        "keywords": dict(keywords={"ra": 1.5, "r e": 0.8, "nn": -2.0}),
+        "eos_terminal": dict(eos=["predict", 18, 1.0, 0.0], eos_is_terminal=True),
+        "eos_blank": dict(eos=["blank", 18]),
+        "eos_ignore": dict(eos=["ignore", 12]),
+        "eos_predict_beta": dict(eos=["predict", 18, 0.8, 0.3]),
+    }
+    beam_out = {}
+    for tag, kw in beam_cases.items():
+        args = dict(kw)
+        eos = args.pop("eos", None)
+        strategy = None if eos is None else {"predict": EOSPredict, "blank": EOSBlank, "ignore": EOSIgnore}[eos[0]](*eos[1:])
+        if "keywords" in args:
+            kpath = os.path.join(OUT, "_kw_tmp.json")
+            json.dump({"keywords": args.pop("keywords")}, open(kpath, "w"))
+            args["keyword_boost_path"] = kpath
+        dec = RNNTBeamDecoder(model=m, blank_idx=V - 1, eos_strategy=strategy, sentpiece_model=spm, **args)
+        res = dec.decode(torch.tensor(g["x"]), torch.tensor(g["x_lens"]))
+        if "keyword_boost_path" in args:
+            os.remove(args["keyword_boost_path"])
+        per_utt = []
+        for r in res:
+            tk, ts, cf, frames, parts = [], [], [], [], {}
+            for t in sorted(r):
+                if r[t].final is not None:
+                    a = r[t].final.alternatives[0]
+                    tk += a.y_seq
+                    ts += a.timesteps
+                    cf += a.confidence
+                    frames.append(t)
+                if r[t].partials is not None:
+                    parts[t] = dict(start=r[t].partials.start_frame_idx, dur=r[t].partials.duration_frames,
+                                    alts=[[h.y_seq, h.timesteps] for h in r[t].partials.alternatives])
+            per_utt.append(dict(tokens=tk, timesteps=ts, confidence=cf, final_frames=frames, last_key=max(r),
+                                partials=parts))
+        beam_out[tag] = dict(kwargs=kw, utts=per_utt)
+        print("beam", tag, [len(u["tokens"]) for u in per_utt], [u["last_key"] for u in per_utt])
+    json.dump(dict(pieces=pieces, unk_bias=-30.0, results=beam_out), open(os.path.join(OUT, "beam_mfma.json"), "w"))
 
     # ---- 3. small pure functions ---------------------------------------------------------
     torch.manual_seed(7)

@@ -49,3 +49,45 @@ def unpack(packed_rows, f_len, y_len, T, U1, fill=0.0):
             (f_len[b], y_len[b] + 1) + packed_rows.shape[1:])
         off += n
     return out
+
+
+class OracleRNNT:
+    """Minimal `encode / predict / joint` object backed by the CPU oracle (oracle/model.py), so that host-side
+    decoders can be exercised without a GPU.  Test infrastructure only."""
+
+    def __init__(self, sd, cfg):
+        import torch
+
+        self.sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+        self.cfg = cfg
+        self.training = False
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def encode(self, x, x_lens, enc_state=None):
+        from oracle import model as om
+
+        f, lens = om.encode(self.sd, self.cfg, x, x_lens)
+        return f, lens, None
+
+    def predict(self, y, pred_state=None, add_sos=True, special_sos=None):
+        import torch
+        from oracle import model as om
+
+        if y is None:  # one zero-embedding step
+            B = 1 if pred_state is None else pred_state[0].size(1)
+            g, st = om.predict(self.sd, self.cfg, torch.zeros(B, 0, dtype=torch.long), pred_state, add_sos=True)
+        else:
+            g, st = om.predict(self.sd, self.cfg, y, pred_state, add_sos=add_sos)
+        return g, st, None
+
+    def joint(self, f, g, *a, **k):
+        from oracle import model as om
+
+        return om.joint(self.sd, f, g)

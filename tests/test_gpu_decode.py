@@ -99,3 +99,39 @@ def test_streaming_equals_offline():
                 got_frames[b] += [enc_frame] * int(n[b])
             enc_frame += 1
     assert got == toks and got_frames == frames
+
+
+@pytest.mark.parametrize("tag", ["default", "capped", "wide", "partials", "forced_finals", "keywords", "eos_blank",
+                                 "eos_terminal", "sample_cap"])
+def test_beam_matches_reference_decoder(tag, tmp_path):
+    """Beam search with the prediction / joint steps on the HIP kernels: the finals (token ids, frames, the frames
+    they were shipped on) and every partial equal the REFERENCE decoder's on the golden mini model."""
+    from tests.test_beam_host import BEAM, build_decoder_from_case, check_against_reference
+
+    g, m = build("mfma")
+    with torch.no_grad():
+        m.joint_fc.bias[0] = BEAM["unk_bias"]
+    case = BEAM["results"][tag]
+    dec = build_decoder_from_case(m, int(g["n_classes"]), case, tmp_path)
+    res = dec.decode(torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV))
+    check_against_reference(res, case, conf_atol=1e-4)
+
+
+def test_beam_expander_batches_hypotheses():
+    """One device step for N hypotheses == N single steps (scores, survivors, states)."""
+    from caiman_asr_amd.rnnt.beam import BeamExpander
+
+    g, m = build("mfma")
+    V = int(g["n_classes"])
+    ex = BeamExpander(m, V - 1)
+    f, _, _ = m.encode(torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV))
+    fr = f[:, 2:3]
+    first = ex.expand(fr, None, None)
+    y = torch.tensor([[3], [7], [11]], device=DEV)
+    state = (torch.cat([e.pred_state[0] for e in first], 1), torch.cat([e.pred_state[1] for e in first], 1))
+    both = ex.expand(fr, y, state)
+    for i in range(3):
+        one = ex.expand(fr[i:i + 1], y[i:i + 1], (state[0][:, i:i + 1].contiguous(), state[1][:, i:i + 1].contiguous()))[0]
+        assert one.tokens.tolist() == both[i].tokens.tolist()
+        assert torch.allclose(one.scores, both[i].scores, atol=1e-5) and abs(one.blank_logp - both[i].blank_logp) < 1e-5
+        assert torch.allclose(one.pred_state[0], both[i].pred_state[0], atol=1e-6)
