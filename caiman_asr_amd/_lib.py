@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcaiman_rnnt.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "caiman_rnnt.h")
+HEADERS = sorted(glob.glob(os.path.join(os.path.dirname(HEADER), "*.h")))
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
@@ -34,7 +35,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [HEADER]
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -46,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     objs, procs = [], []
-    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) + [HEADER])
+    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) + HEADERS)
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
@@ -83,6 +84,16 @@ class BwdSlot(ctypes.Structure):
                 ("parity", ctypes.c_int32), ("nsteps", ctypes.c_int32), ("has_next", ctypes.c_int32),
                 ("drop_p", ctypes.c_float), ("drop_counter", ctypes.c_uint64)]
 
+class BeamConfig(ctypes.Structure):
+    """caiman_beam_config_t (include/caiman_beam.h)."""
+    _fields_ = [("blank_idx", ctypes.c_int32), ("beam_width", ctypes.c_int32),
+                ("max_symbols_per_step", ctypes.c_int32), ("max_symbol_per_sample", ctypes.c_int32),
+                ("beam_prune_score_thresh", ctypes.c_double), ("beam_prune_topk_thresh", ctypes.c_double),
+                ("eos_vad_threshold", ctypes.c_double), ("final_emission_thresh", ctypes.c_double),
+                ("frame_width", ctypes.c_double), ("eos_terminal_idx", ctypes.c_int32),
+                ("return_partials", ctypes.c_int32)]
+
+
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -116,14 +127,30 @@ _SIGS = {
     "caiman_lamb_step": ([P, P, P, P, P, P, P, P, I64, P, P, I64, P, P, I32, F32, F32, F32, F32, F32, F32, I32, I32,
                           I32, P, P, P], ctypes.c_int),
     "caiman_lstm_fused_bwd": ([P, P, P, P, I64, I64, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
+    # include/caiman_beam.h
+    "caiman_beam_topk": ([P, I64, I64, I64, I32, F32, I32, I32, I32, F32, F32, I32, P, P, P, P], ctypes.c_int),
+    "caiman_beam_create": ([ctypes.POINTER(BeamConfig), I32, ctypes.POINTER(ctypes.c_char_p), I32,
+                            ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), I32], ctypes.c_void_p),
+    "caiman_beam_destroy": ([P], None),
+    "caiman_beam_reset_stream": ([P, I32], ctypes.c_int),
+    "caiman_beam_push_frame": ([P, P, I32], ctypes.c_int),
+    "caiman_beam_requests": ([P, P, P, P, P, P, I64], ctypes.c_int64),
+    "caiman_beam_feed": ([P, I64, I32, P, P, P], ctypes.c_int),
+    "caiman_beam_close_stream": ([P, I32], ctypes.c_int),
+    "caiman_beam_stream_done": ([P, I32], ctypes.c_int),
+    "caiman_beam_state_slots": ([P], ctypes.c_int64),
+    "caiman_beam_responses": ([P, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.POINTER(ctypes.c_int64),
+                               ctypes.POINTER(ctypes.POINTER(ctypes.c_float)), ctypes.POINTER(ctypes.c_int64)],
+                              ctypes.c_int),
+    "caiman_beam_clear_responses": ([P], None),
 }
 
 
 def exported_symbols():
-    """Names declared in include/caiman_rnnt.h (used by the CPU-side ABI test)."""
+    """Names declared in include/*.h (used by the CPU-side ABI test)."""
     import re
 
-    text = open(HEADER).read()
+    text = "".join(open(h).read() for h in HEADERS)
     return sorted(set(re.findall(r"\b(caiman_[a-z0-9_]+)\s*\(", text)))
 
 

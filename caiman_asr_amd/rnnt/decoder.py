@@ -219,6 +219,36 @@ def flatten_responses(responses: List[Dict[int, FrameResponses]]):
     return toks, frames, confs
 
 
+class StreamingEncoder:
+    """Encoder of B concurrent streams advanced chunk by chunk: pre-rnn with carried (h, c), StackTime over a
+    carried remainder of pre-rnn frames, post-rnn with carried (h, c), joint_enc projection."""
+
+    def __init__(self, model, n_streams: int):
+        self.model = getattr(model, "module", model)
+        self.B = n_streams
+        self.enc_state: Optional[EncoderState] = None
+        self.carry = None  # pre-rnn output frames not yet consumed by StackTime
+
+    @torch.no_grad()
+    def advance(self, feats: torch.Tensor) -> Optional[torch.Tensor]:
+        """feats [n, B, in_feats] -> encoder frames completed by this chunk, [B, n_enc, Hj], or None."""
+        m, B = self.model, self.B
+        factor = m.enc_stack_time_factor
+        x, pre_state, _ = m.encoder["pre_rnn"](feats, self.enc_state.pre_rnn if self.enc_state else None)
+        if self.carry is not None:
+            x = torch.cat([self.carry, x], 0)
+        n_full = (x.shape[0] // factor) * factor
+        self.carry = x[n_full:] if n_full < x.shape[0] else None
+        post_prev = self.enc_state.post_rnn if self.enc_state else None
+        if n_full == 0:
+            self.enc_state = EncoderState(pre_rnn=pre_state, post_rnn=post_prev)
+            return None
+        xs = x[:n_full].view(n_full // factor, factor, B, -1).transpose(1, 2).reshape(n_full // factor, B, -1)
+        y, post_state, _ = m.encoder["post_rnn"](xs, post_prev)
+        self.enc_state = EncoderState(pre_rnn=pre_state, post_rnn=post_state)
+        return m.joint_enc(y.transpose(0, 1))
+
+
 class StreamingGreedyDecoder:
     """Thousands of concurrent real-time streams on one GPU: every `step()` takes the next chunk of
     spliced features for ALL streams ([frames, B, in_feats]; 2 frames = 60 ms at the base config),
@@ -232,8 +262,7 @@ class StreamingGreedyDecoder:
                                             max_symbols_per_step=max_symbols_per_step, sync_every=1)
         self.model = self.dec.model
         self.B = n_streams
-        self.enc_state: Optional[EncoderState] = None
-        self.carry = None  # pre-rnn output frames not yet consumed by StackTime
+        self.encoder = StreamingEncoder(self.model, n_streams)
         self.pred = None
         self.frames_seen = 0
 
@@ -244,20 +273,9 @@ class StreamingGreedyDecoder:
         m.eval()
         dev = feats.device
         B = self.B
-        factor = m.enc_stack_time_factor
-        x, pre_state, _ = m.encoder["pre_rnn"](feats, self.enc_state.pre_rnn if self.enc_state else None)
-        if self.carry is not None:
-            x = torch.cat([self.carry, x], 0)
-        n_full = (x.shape[0] // factor) * factor
-        self.carry = x[n_full:] if n_full < x.shape[0] else None
-        post_prev = self.enc_state.post_rnn if self.enc_state else None
-        if n_full == 0:
-            self.enc_state = EncoderState(pre_rnn=pre_state, post_rnn=post_prev)
+        f_all = self.encoder.advance(feats)  # [B, n_enc, Hj]
+        if f_all is None:
             return []
-        xs = x[:n_full].view(n_full // factor, factor, B, -1).transpose(1, 2).reshape(n_full // factor, B, -1)
-        y, post_state, _ = m.encoder["post_rnn"](xs, post_prev)
-        self.enc_state = EncoderState(pre_rnn=pre_state, post_rnn=post_state)
-        f_all = m.joint_enc(y.transpose(0, 1))  # [B, n_enc, Hj]
         if self.pred is None:
             self.pred = self.dec._initial_state(B, dev, torch.ones(B, dtype=torch.long, device=dev))
             self.pred["max_off"].fill_(1 << 40)  # a live stream is never "at the last frame"

@@ -1,0 +1,115 @@
+/*
+ * caiman_beam.h — C-ABI of the beam-search decoder for thousands of concurrent streams.
+ *
+ * Two halves, both behind plain C entry points:
+ *
+ *  (1) caiman_beam_topk — DEVICE: what the reference computes per expansion round with
+ *      `log_softmax(logits / T)`, the EOS strategy, `topk(beam_width)` and the blank column
+ *      (training/caiman_asr_train/rnnt/decoder.py:139-172, beam.py:533-546), as one pass over the
+ *      logits of all pending hypotheses; fixed-shape outputs so one D2H copy brings them back.
+ *
+ *  (2) caiman_beam_* search object — HOST: the per-utterance search the reference runs as Python
+ *      generators (beam.py:285-516: best-first expansion of the open set, hypothesis merging by text
+ *      hash hypothesis.py:114-122, width / length-normalised pruning beam.py:661-683, common-prefix
+ *      finals and partials serialise_responses.py:28-205, keyword boosting keywords/trie.py), restated
+ *      as one object that owns every stream's beam.  Frames are pushed as they arrive, so the same
+ *      object serves offline batches and real-time streams.
+ *
+ * Prediction-network states never leave the device: the search refers to them by SLOT index into a
+ * pool the caller keeps in HBM ([layers, slots, hidden] for h and c).  Per round the caller
+ *     n = caiman_beam_requests(...)      -> (stream, last token, state slot in, state slot out) per pending hypothesis
+ *     gathers states by slot, runs prediction + joint + caiman_beam_topk, scatters new states to `slot out`
+ *     caiman_beam_feed(...)              <- top-k scores / tokens / blank log-prob per request
+ * until no stream has a request left for the frames pushed so far.
+ *
+ * Every function returns 0 on success (or a count where stated) and a non-zero code with
+ * caiman_last_error() set otherwise.  Host functions are not thread-safe per handle.
+ */
+#ifndef CAIMAN_BEAM_H_
+#define CAIMAN_BEAM_H_
+
+#include <stdint.h>
+
+#include "caiman_rnnt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* EOS handling of the reference's decoders (rnnt/eos_strategy.py:7-27, decoder.py:139-157). */
+typedef enum {
+  CAIMAN_EOS_NONE = 0,
+  CAIMAN_EOS_IGNORE = 1,  /* log p(eos) = -inf */
+  CAIMAN_EOS_BLANK = 2,   /* p(blank) += p(eos); log p(eos) = -inf */
+  CAIMAN_EOS_PREDICT = 3  /* log p(eos) *= alpha; -inf unless > log(beta) (beta > 0) */
+} caiman_eos_mode_t;
+
+/* logits [n, vocab] (dtype tag, `row_stride` elements between rows) ->
+ *   top_scores [n, k] f32 (descending), top_tokens [n, k] i32, blank_logp [n] f32
+ * of log_softmax(logits / temperature) after the EOS correction.  k <= 8, k <= vocab.
+ * Ties resolve to the lower token id. */
+int caiman_beam_topk(const void* logits, int64_t n, int64_t vocab, int64_t row_stride, int dtype,
+                     float temperature, int32_t blank_idx, int eos_mode, int32_t eos_idx,
+                     float eos_alpha, float eos_beta, int32_t k, float* top_scores,
+                     int32_t* top_tokens, float* blank_logp, caiman_stream_t stream);
+
+/* Search parameters: constructor arguments of RNNTBeamDecoder (beam.py:115-137). Thresholds < 0 mean
+ * "off" (infinite), as in the reference (:153-154,190-200). */
+typedef struct {
+  int32_t blank_idx;
+  int32_t beam_width;
+  int32_t max_symbols_per_step;   /* <= 0: unlimited */
+  int32_t max_symbol_per_sample;  /* < 0: unlimited */
+  double beam_prune_score_thresh; /* nats per token */
+  double beam_prune_topk_thresh;  /* nats */
+  double eos_vad_threshold;       /* seconds of silence that end a stream */
+  double final_emission_thresh;   /* seconds without a final before the beam is forced to agree */
+  double frame_width;             /* seconds per encoder frame */
+  int32_t eos_terminal_idx;       /* token that ends a stream when predicted, or -1 */
+  int32_t return_partials;
+} caiman_beam_config_t;
+
+typedef struct caiman_beam caiman_beam_t;
+
+/* pieces: UTF-8 text of every token id (sentencepiece id_to_piece); keywords: phrases (spaces already
+ * replaced by U+2581) with their per-symbol weights, or n_keywords = 0.  Returns NULL on error. */
+caiman_beam_t* caiman_beam_create(const caiman_beam_config_t* cfg, int32_t n_streams,
+                                  const char* const* pieces, int32_t n_pieces,
+                                  const char* const* keywords, const double* keyword_weights,
+                                  int32_t n_keywords);
+void caiman_beam_destroy(caiman_beam_t* h);
+
+/* Start a new utterance on `stream` (drops its beam, frees its state slots). */
+int caiman_beam_reset_stream(caiman_beam_t* h, int32_t stream);
+/* The next encoder frame of each listed stream is available: opens that frame's expansion.  Streams that
+ * have ended (terminal token, silence, symbol budget) ignore it.  A stream must have no open frame. */
+int caiman_beam_push_frame(caiman_beam_t* h, const int32_t* streams, int32_t n);
+/* Pending expansions, one per stream with an open frame.  y_last = -1 and state_in = -1 mark the
+ * start-of-sequence step (zero embedding, zero state).  state_out is a fresh slot the caller must fill
+ * with the new prediction state.  Returns the count (<= cap), or -1 on error. */
+int64_t caiman_beam_requests(caiman_beam_t* h, int32_t* stream, int32_t* frame, int32_t* y_last,
+                             int32_t* state_in, int32_t* state_out, int64_t cap);
+/* Answers for exactly the requests returned by the last caiman_beam_requests call, in order:
+ * top_scores / top_tokens [n, k] as written by caiman_beam_topk, blank_logp [n] (host pointers). */
+int caiman_beam_feed(caiman_beam_t* h, int64_t n, int32_t k, const float* top_scores,
+                     const int32_t* top_tokens, const float* blank_logp);
+/* No more audio on `stream`: ships what the best hypothesis still holds (one frame after the last). */
+int caiman_beam_close_stream(caiman_beam_t* h, int32_t stream);
+/* 1 if the stream has ended by itself or was closed. */
+int caiman_beam_stream_done(const caiman_beam_t* h, int32_t stream);
+/* Number of state slots the device pool must hold (grows; check after caiman_beam_requests). */
+int64_t caiman_beam_state_slots(const caiman_beam_t* h);
+
+/* Responses accumulated since the last clear, as two flat arrays that stay valid until the next call
+ * on the handle.  ints: a sequence of records
+ *     stream, frame_key, kind (0 final | 1 partials | 2 frame closed with neither), start_frame, duration_frames,
+ *     n_alternatives, then per alternative: n_tokens, token ids..., frame indices...
+ * floats: the confidences of all alternatives in the same order. */
+int caiman_beam_responses(caiman_beam_t* h, const int32_t** ints, int64_t* n_ints,
+                          const float** floats, int64_t* n_floats);
+void caiman_beam_clear_responses(caiman_beam_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAIMAN_BEAM_H_ */

@@ -91,3 +91,32 @@ class OracleRNNT:
         from oracle import model as om
 
         return om.joint(self.sd, f, g)
+
+
+class OracleBeamStep:
+    """CPU stand-in for the HIP expansion round of caiman_asr_amd.rnnt.beam_native (prediction + joint via the
+    oracle-backed model, log-softmax / EOS correction / top-k via torch): lets the native search object be driven
+    through its C-ABI without a GPU.  Test infrastructure only."""
+
+    def __init__(self, decoder, model):
+        import torch
+
+        self.dec, self.model, self.torch = decoder, model, torch
+        self.states = {}
+
+    def __call__(self, f, y_last, state_in, state_out, n_slots):
+        import numpy as np
+
+        torch, k = self.torch, self.dec.beam_width
+        sc, tk, bl = [], [], []
+        for i in range(len(y_last)):
+            if y_last[i] < 0:
+                g, st, _ = self.model.predict(None, None, add_sos=False)
+            else:
+                g, st, _ = self.model.predict(torch.tensor([[int(y_last[i])]]), self.states[int(state_in[i])], add_sos=False)
+            self.states[int(state_out[i])] = st
+            log_p = self.dec._joint_step(f[i:i + 1], g)
+            s, t = log_p.topk(min(k, log_p.shape[1]), dim=1)
+            sc.append(s[0].numpy()); tk.append(t[0].numpy().astype(np.int32)); bl.append(float(log_p[0, self.dec.blank_idx]))
+        return (np.ascontiguousarray(np.stack(sc), dtype=np.float32), np.ascontiguousarray(np.stack(tk), dtype=np.int32),
+                np.asarray(bl, dtype=np.float32))

@@ -19,7 +19,7 @@ from caiman_asr_amd.rnnt.beam import RNNTBeamDecoder
 from caiman_asr_amd.rnnt.decoder import flatten_responses
 from caiman_asr_amd.rnnt.hypothesis import Hypothesis, init_sos_hyp, roll_hash
 from caiman_asr_amd.rnnt.serialise_responses import ResponseSerializer
-from tests.helpers import OracleRNNT
+from tests.helpers import OracleBeamStep, OracleRNNT
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 BEAM = json.load(open(os.path.join(GOLD, "beam_mfma.json")))
@@ -160,7 +160,7 @@ def _oracle_model():
     return g, OracleRNNT(sd, json.loads(str(g["cfg"])))
 
 
-def build_decoder_from_case(model, V, case, tmp_path):
+def build_decoder_from_case(model, V, case, tmp_path, native=False, oracle_step=False):
     """kwargs as stored by oracle/gen_golden.py: `eos` = [kind, idx, (alpha, beta)], `keywords` = {phrase: weight}."""
     from caiman_asr_amd.rnnt.eos_strategy import EOSBlank, EOSIgnore, EOSPredict
 
@@ -171,7 +171,15 @@ def build_decoder_from_case(model, V, case, tmp_path):
         kp = tmp_path / "kw.json"
         kp.write_text(json.dumps({"keywords": args.pop("keywords")}))
         args["keyword_boost_path"] = str(kp)
-    return RNNTBeamDecoder(model, blank_idx=V - 1, eos_strategy=strategy, sentpiece_model=PIECES, **args)
+    if not native:
+        return RNNTBeamDecoder(model, blank_idx=V - 1, eos_strategy=strategy, sentpiece_model=PIECES, **args)
+    from caiman_asr_amd.rnnt.beam_native import RNNTBeamDecoderNative
+
+    dec = RNNTBeamDecoderNative(model, blank_idx=V - 1, eos_strategy=strategy, sentpiece_model=PIECES,
+                                device_step=(lambda *a: None) if oracle_step else None, **args)
+    if oracle_step:
+        dec.step = OracleBeamStep(dec, model)
+    return dec
 
 
 def check_against_reference(res, case, conf_atol=1e-5):
@@ -199,6 +207,59 @@ def test_beam_matches_reference_finals(tag, tmp_path):
     case = BEAM["results"][tag]
     dec = build_decoder_from_case(m, V, case, tmp_path)
     check_against_reference(dec.decode(torch.tensor(g["x"]), torch.tensor(g["x_lens"])), case)
+
+
+@pytest.mark.parametrize("tag", sorted(BEAM["results"]))
+def test_native_search_matches_reference_finals(tag, tmp_path):
+    """The C++ search object (include/caiman_beam.h) driven through its C-ABI, network evaluated by the oracle."""
+    g, m = _oracle_model()
+    case = BEAM["results"][tag]
+    dec = build_decoder_from_case(m, int(g["n_classes"]), case, tmp_path, native=True, oracle_step=True)
+    check_against_reference(dec.decode(torch.tensor(g["x"]), torch.tensor(g["x_lens"])), case)
+
+
+@pytest.mark.parametrize("thresholds, tokens", [((0.4, 1.5), [2, 3, 4]), ((-1, -1), [5, 2, 3])])
+def test_native_search_mock_model_known_answers(thresholds, tokens):
+    from caiman_asr_amd.rnnt.beam_native import RNNTBeamDecoderNative
+
+    m = MockModel(6)
+    dec = RNNTBeamDecoderNative(m, blank_idx=0, eos_strategy=None, sentpiece_model=PIECES, beam_width=4,
+                                temperature=1.5, max_symbols_per_step=8, beam_prune_score_thresh=thresholds[0],
+                                beam_prune_topk_thresh=thresholds[1], return_partials=True, device_step=lambda *a: None)
+    dec.step = OracleBeamStep(dec, m)
+    res = dec.decode(torch.randn(4, 1, 1), torch.tensor([4]))
+    tk, ts, pr = flatten_responses(res)
+    assert tk == [tokens] and ts == [[1, 2, 3]] and pr == [[1.0, 1.0, 1.0]]
+    assert all(r.partials is not None for t, r in res[0].items() if t < 4) and res[0][4].partials is None
+
+
+def test_native_search_abi_errors():
+    from caiman_asr_amd.rnnt.beam_native import NativeBeamSearch
+
+    with pytest.raises(RuntimeError, match="prune threshold"):
+        NativeBeamSearch(2, PIECES, blank_idx=28, beam_prune_topk_thresh=0.0)
+    with pytest.raises(RuntimeError, match="frame_width"):
+        NativeBeamSearch(2, PIECES, blank_idx=28, eos_vad_threshold=1.0)
+    with pytest.raises(RuntimeError, match="duplicated"):
+        NativeBeamSearch(2, PIECES, blank_idx=28, keywords=["ab", "ab"], keyword_weights=[1.0, 2.0])
+    s = NativeBeamSearch(2, PIECES, blank_idx=28)
+    s.push_frame(np.array([0, 1]))
+    with pytest.raises(RuntimeError, match="open frame"):
+        s.push_frame(np.array([0]))
+    stream, frame, y, s_in, s_out = s.requests()
+    assert stream.tolist() == [0, 1] and frame.tolist() == [0, 0] and y.tolist() == [-1, -1] and s_in.tolist() == [-1, -1]
+    assert s_out.tolist() == [0, 1] and s.state_slots() == 2
+    with pytest.raises(RuntimeError, match="not been fed"):
+        s.requests()
+    with pytest.raises(RuntimeError, match="answers for"):
+        s.feed(np.zeros((1, 4), np.float32), np.zeros((1, 4), np.int32), np.zeros(1, np.float32))
+    sc = np.log(np.array([[0.6, 0.2, 0.1, 0.05]] * 2, np.float32))
+    tk = np.array([[28, 3, 4, 5], [3, 28, 4, 5]], np.int32)
+    s.feed(sc, tk, np.log(np.array([0.6, 0.2], np.float32)))
+    with pytest.raises(RuntimeError, match="<unk>"):
+        stream, *_ = s.requests()
+        s.feed(np.log(np.full((len(stream), 4), 0.25, np.float32)), np.zeros((len(stream), 4), np.int32),
+               np.full(len(stream), -3.0, np.float32))
 
 
 def test_beam_limits_and_errors():

@@ -135,3 +135,88 @@ def test_beam_expander_batches_hypotheses():
         assert one.tokens.tolist() == both[i].tokens.tolist()
         assert torch.allclose(one.scores, both[i].scores, atol=1e-5) and abs(one.blank_logp - both[i].blank_logp) < 1e-5
         assert torch.allclose(one.pred_state[0], both[i].pred_state[0], atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("eos", [None, ("ignore", 5), ("blank", 5), ("predict", 5, 0.7, 0.0), ("predict", 5, 1.0, 0.02)])
+def test_beam_topk_kernel(dtype, eos):
+    """caiman_beam_topk == log_softmax(logits / T) -> EOS correction -> topk / blank column (decoder.py:139-172,
+    beam.py:535-546): token ids exact, scores to 1e-5 (fp32 math in both)."""
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt.decoder import RNNTCommonDecoder
+    from caiman_asr_amd.rnnt.eos_strategy import EOSBlank, EOSIgnore, EOSPredict
+
+    torch.manual_seed(3)
+    n, V, k, T, blank = 37, 8704, 4, 1.4, 8703
+    logits = (torch.randn(n, V, device=DEV) * 3).to(dtype)
+    logits[0, 100:104] = logits[0].max() + 1       # exact ties: the lower id wins
+    logits[1, 5] += 12                              # EOS is the best entry of this row
+    logits[2, blank] += 12
+    strat = None if eos is None else {"ignore": EOSIgnore, "blank": EOSBlank, "predict": EOSPredict}[eos[0]](*eos[1:])
+    ref_dec = RNNTCommonDecoder.__new__(RNNTCommonDecoder)
+    ref_dec.eos_strategy, ref_dec.blank_idx = strat, blank
+    lp = ref_dec._eos_prob_correction(torch.log_softmax(logits.float() / T, dim=-1))
+    ref_s, ref_i = lp.topk(k, dim=1)
+    sc = torch.empty(n, k, device=DEV)
+    tk = torch.empty(n, k, dtype=torch.int32, device=DEV)
+    bl = torch.empty(n, device=DEV)
+    mode = (0, 0, 1.0, 0.0) if eos is None else ({"ignore": 1, "blank": 2, "predict": 3}[eos[0]], eos[1],
+                                                 *(eos[2:] if len(eos) > 2 else (1.0, 0.0)))
+    _lib.check(_lib.lib().caiman_beam_topk(_lib.ptr(logits), n, V, logits.stride(0), _lib.dtype_tag(dtype), T, blank,
+                                           mode[0], mode[1], mode[2], mode[3], k, _lib.ptr(sc), _lib.ptr(tk),
+                                           _lib.ptr(bl), _lib.stream()))
+    assert torch.allclose(sc, ref_s, atol=1e-5)
+    assert torch.allclose(bl, lp[:, blank], atol=1e-5)
+    assert tk[0].tolist() == [100, 101, 102, 103]
+    distinct = (ref_s[:, :-1] - ref_s[:, 1:]).min(dim=1).values > 1e-4          # rows without near-ties
+    assert distinct.sum() > n // 2 and torch.equal(tk[distinct].long(), ref_i[distinct])
+    # strided rows
+    wide = torch.zeros(n, V + 64, device=DEV, dtype=dtype)
+    wide[:, :V] = logits
+    _lib.check(_lib.lib().caiman_beam_topk(_lib.ptr(wide), n, V, wide.stride(0), _lib.dtype_tag(dtype), T, blank,
+                                           mode[0], mode[1], mode[2], mode[3], k, _lib.ptr(sc), _lib.ptr(tk),
+                                           _lib.ptr(bl), _lib.stream()))
+    assert torch.allclose(sc, ref_s, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["default", "capped", "wide", "partials", "forced_finals", "vad", "sample_cap", "keywords",
+                                 "eos_terminal", "eos_blank", "eos_ignore", "eos_predict_beta"])
+def test_native_beam_matches_reference_decoder(tag, tmp_path):
+    """The serving path (C++ search + HIP round with states in the slot pool) equals the REFERENCE decoder."""
+    from tests.test_beam_host import BEAM, build_decoder_from_case, check_against_reference
+
+    g, m = build("mfma")
+    with torch.no_grad():
+        m.joint_fc.bias[0] = BEAM["unk_bias"]
+    case = BEAM["results"][tag]
+    dec = build_decoder_from_case(m, int(g["n_classes"]), case, tmp_path, native=True)
+    res = dec.decode(torch.tensor(g["x"], device=DEV), torch.tensor(g["x_lens"], device=DEV))
+    check_against_reference(res, case, conf_atol=1e-4)
+
+
+def test_streaming_beam_equals_offline():
+    """Chunked audio with carried encoder / beam state gives the finals of the offline decode, per stream."""
+    from caiman_asr_amd.rnnt.beam_native import RNNTBeamDecoderNative, StreamingBeamDecoder
+    from caiman_asr_amd.rnnt.decoder import flatten_responses
+    from tests.test_beam_host import BEAM, PIECES
+
+    g, m = build("mfma")
+    with torch.no_grad():
+        m.joint_fc.bias[0] = BEAM["unk_bias"]
+    V = int(g["n_classes"])
+    torch.manual_seed(5)
+    T, B = 24, 6
+    x = torch.randn(T, B, g["x"].shape[2], device=DEV)
+    off = RNNTBeamDecoderNative(m, V - 1, None, PIECES).decode(x, torch.full((B,), T, device=DEV))
+    dec = StreamingBeamDecoder(m, V - 1, B, PIECES)
+    merged = [dict() for _ in range(B)]
+    for t0 in range(0, T, 4):
+        for b, r in enumerate(dec.step(x[t0:t0 + 4])):
+            merged[b].update(r)
+    for b, r in enumerate(dec.close()):
+        merged[b].update(r)
+    (tk_s, ts_s, cf_s), (tk_o, ts_o, cf_o) = flatten_responses(merged), flatten_responses(off)
+    assert tk_s == tk_o and ts_s == ts_o and sum(map(len, tk_o)) > 10
+    for a, b in zip(cf_s, cf_o):                 # batch shapes differ between the two runs: GEMM rounding only
+        assert np.allclose(a, b, atol=1e-4)
+    assert [sorted(r) for r in merged] == [sorted(r) for r in off]
