@@ -1,4 +1,5 @@
-"""bench_decode.py — real-time streams per GPU for streaming greedy decode (second half of the BASELINE metric).
+"""bench_decode.py — real-time streams per GPU for streaming greedy / beam decode (second half of the BASELINE metric;
+`--decoder beam` is BASELINE.json configs[4]: beam width 4, temperature 1.4, max 8 symbols per frame).
 
 N concurrent 16 kHz streams; every tick each stream delivers 60 ms of audio = 2 spliced feature frames
 ([2, N, 240]).  A tick = encoder advance with carried LSTM state (2 pre-rnn steps, StackTime,
@@ -32,6 +33,11 @@ def main():
     ap.add_argument("--emit-rate", type=float, default=0.2, help="target P(non-blank) per joint evaluation")
     ap.add_argument("--logit-scale", type=float, default=30.0, help="widen random-init logits so decisions vary")
     ap.add_argument("--max-symbols", type=int, default=8)
+    ap.add_argument("--decoder", choices=["greedy", "beam"], default="greedy")
+    ap.add_argument("--beam-width", type=int, default=4)
+    ap.add_argument("--top1-prob", type=float, default=0.85,
+                    help="beam: mean top-1 probability of softmax(logits/1.4) the synthetic logits are scaled to (0 = keep --logit-scale)")
+    ap.add_argument("--profile-host", action="store_true", help="beam: split the tick into host / device parts")
     args = ap.parse_args()
     from caiman_asr_amd import _lib
     from caiman_asr_amd.rnnt.decoder import StreamingGreedyDecoder
@@ -46,14 +52,44 @@ def main():
         # random-init logits are almost constant: widen them, then place the blank bias at the quantile that
         # makes a joint evaluation emit a non-blank with probability `emit_rate` (3.3 tokens/s over 16.7
         # encoder frames/s is ~0.2 for read speech)
-        model.joint_net[2].weight.mul_(args.logit_scale)
         probe = torch.randn(40, 256, 240, device=dev)
         f, _, _ = model.encode(probe, torch.full((256,), 40, device=dev))
         g, _, _ = model.predict(None, None, add_sos=False)
-        logits = model.joint(f[:, -4:].reshape(-1, 1, f.shape[-1]), g.expand(f.shape[0] * 4, -1, -1))[:, 0, 0].float()
-        margin = logits[:, :-1].max(-1).values - logits[:, -1]
-        model.joint_net[2].bias[N_CLASSES - 1] += torch.quantile(margin, 1.0 - args.emit_rate).item()
-    dec = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=args.streams, max_symbols_per_step=args.max_symbols)
+        raw = model.joint(f[:, -4:].reshape(-1, 1, f.shape[-1]), g.expand(f.shape[0] * 4, -1, -1))[:, 0, 0].float()
+        raw[:, 0] = -1e4 if args.decoder == "beam" else raw[:, 0]
+
+        def blank_shift(scale):   # bias that makes P(argmax != blank) = emit_rate at this scale
+            margin = scale * (raw[:, :-1].max(-1).values - raw[:, -1])
+            return torch.quantile(margin, 1.0 - args.emit_rate).item()
+
+        scale = args.logit_scale
+        if args.decoder == "beam" and args.top1_prob > 0:
+            # a trained transducer is confident: pick the scale at which the mean top-1 probability of
+            # softmax(logits / 1.4) is `top1_prob` (bisection; the blank bias is re-fitted at every scale)
+            lo, hi = 1.0, 4096.0
+            for _ in range(30):
+                scale = (lo * hi) ** 0.5
+                z = scale * raw
+                z[:, -1] += blank_shift(scale)
+                top1 = torch.softmax(z / 1.4, -1).max(-1).values.mean().item()
+                lo, hi = (scale, hi) if top1 < args.top1_prob else (lo, scale)
+        model.joint_net[2].weight.mul_(scale)
+        model.joint_net[2].bias.mul_(scale)
+        model.joint_net[2].bias[N_CLASSES - 1] += blank_shift(scale)
+    if args.decoder == "beam":
+        from caiman_asr_amd.rnnt.beam_native import StreamingBeamDecoder
+
+        with torch.no_grad():   # id 0 is <unk>: the search refuses it, a trained model never emits it
+            model.joint_net[2].weight[0].zero_()
+            model.joint_net[2].bias[0] = -1e4
+        # synthetic vocabulary: unique lower-case strings, every third one starts a word
+        letters = "abcdefghijklmnopqrstuvwxyz"
+        pieces = ["<unk>"] + [("\u2581" if i % 3 == 0 else "") + "".join(letters[(i // 26 ** d) % 26] for d in range(3))
+                              for i in range(1, N_CLASSES - 1)]
+        dec = StreamingBeamDecoder(model, N_CLASSES - 1, args.streams, pieces, beam_width=args.beam_width,
+                                   max_symbols_per_step=args.max_symbols, temperature=1.4)
+    else:
+        dec = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=args.streams, max_symbols_per_step=args.max_symbols)
     feats = [torch.randn(2, args.streams, 240, device=dev) for _ in range(8)]
     lat, tokens, frames = [], 0, 0
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -61,17 +97,32 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = dec.step(feats[i % 8])
-            n_tok = sum(int(n.sum().item()) for _, n in out)  # results on the host = end of the tick
+            if args.decoder == "beam":   # responses are host objects already
+                n_tok = sum(len(r.final.alternatives[0].y_seq) for per in out for r in per.values() if r.final)
+                n_frames = 1
+            else:
+                n_tok = sum(int(n.sum().item()) for _, n in out)  # results on the host = end of the tick
+                n_frames = len(out)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            if i == args.warmup - 1 and args.decoder == "beam" and args.profile_host:
+                import collections
+
+                dec.dec.profile = collections.defaultdict(float)
             if i >= args.warmup:
                 lat.append(dt)
                 tokens += n_tok
-                frames += len(out) * args.streams
+                frames += n_frames * args.streams
     lat.sort()
     p50, p99, worst = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.99 * len(lat)))], lat[-1]
+    if args.decoder == "beam" and args.profile_host:
+        print("[host profile, ms per tick]", {k: round(v * 1e3 / args.ticks, 3) if k not in ("rounds", "expansions")
+                                              else v / args.ticks for k, v in dec.dec.profile.items()}, file=sys.stderr)
     print(json.dumps({
-        "metric": "real-time streams per GPU (streaming greedy decode, base RNN-T)", "streams": args.streams,
+        "metric": f"real-time streams per GPU (streaming {args.decoder} decode, base RNN-T)", "streams": args.streams,
+        **({"beam_width": args.beam_width, "temperature": 1.4,
+            "expansion_rounds_per_tick": dec.rounds / max(args.warmup + args.ticks, 1),
+            "synthetic_top1_prob": args.top1_prob, "logit_scale": scale} if args.decoder == "beam" else {}),
         "tick_audio_ms": 60.0, "tick_latency_ms": {"p50": p50 * 1e3, "p99": p99 * 1e3, "max": worst * 1e3},
         "real_time": bool(p99 < 0.060), "rtf_p99": p99 / 0.060,
         "max_streams_at_p99_linear_estimate": int(args.streams * 0.060 / p99),

@@ -6,8 +6,14 @@
 // relies on the iteration order of Python dicts (first maximum wins, stable sorts), the containers
 // below are insertion-ordered vectors searched linearly -- beams hold a handful of entries.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
 #include <limits>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -111,6 +117,10 @@ struct Keywords {
 };
 
 // ---- prediction-state slots --------------------------------------------------------------------------
+// Slots are only ever shared between hypotheses of ONE stream, so reference counts need no locking when streams
+// are spread over threads; frees are parked in a per-thread list and merged after the parallel section.
+static thread_local std::vector<int32_t>* tl_freed = nullptr;
+
 struct SlotPool {
   std::vector<int32_t> refs;
   std::vector<int32_t> free_list;
@@ -130,8 +140,77 @@ struct SlotPool {
     if (s >= 0) ++refs[s];
   }
   void release(int32_t s) {
-    if (s >= 0 && --refs[s] == 0) free_list.push_back(s);
+    if (s >= 0 && --refs[s] == 0) (tl_freed ? *tl_freed : free_list).push_back(s);
   }
+};
+
+// ---- persistent worker threads: parallel_for over streams ---------------------------------------------------
+class Workers {
+ public:
+  explicit Workers(int n) : n_(n) {
+    for (int i = 1; i < n_; ++i) threads_.emplace_back([this, i] { loop(i); });
+  }
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+      ++generation_;
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  int size() const { return n_; }
+  // fn(begin, end, worker) over [0, n) in chunks handed out dynamically; the caller is worker 0
+  void run(int64_t n, int64_t chunk, const std::function<void(int64_t, int64_t, int)>& fn) {
+    if (n_ == 1 || n <= chunk) return fn(0, n, 0);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      fn_ = &fn;
+      total_ = n;
+      chunk_ = chunk;
+      next_.store(0);
+      pending_ = n_ - 1;
+      ++generation_;
+    }
+    cv_.notify_all();
+    work(0);
+    std::unique_lock<std::mutex> g(mu_);
+    done_cv_.wait(g, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work(int id) {
+    for (;;) {
+      const int64_t b = next_.fetch_add(chunk_);
+      if (b >= total_) return;
+      (*fn_)(b, std::min(total_, b + chunk_), id);
+    }
+  }
+  void loop(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      work(id);
+      std::lock_guard<std::mutex> g(mu_);
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  int n_;
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int64_t, int64_t, int)>* fn_ = nullptr;
+  int64_t total_ = 0, chunk_ = 1;
+  std::atomic<int64_t> next_{0};
+  int pending_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
 };
 
 // ---- hypothesis (hypothesis.py:38-162) -----------------------------------------------------------------
@@ -240,9 +319,19 @@ struct caiman_beam {
   std::vector<Stream> streams;
   std::vector<int32_t> live;  // streams with an open frame
   std::vector<Request> pending;
+  // response records: written per worker thread, gathered into out_i / out_f when the host asks for them
+  struct Out {
+    std::vector<int32_t> i;
+    std::vector<float> f;
+    std::vector<int32_t> freed;
+  };
+  std::vector<Out> outs{1};
+  static thread_local Out* tl_out;
   std::vector<int32_t> out_i;
   std::vector<float> out_f;
-  bool saw_unk = false;
+  std::atomic<bool> saw_unk{false};
+  std::unique_ptr<Workers> workers;
+  Out& out() { return tl_out ? *tl_out : outs[0]; }
 
   // ---- text helpers --------------------------------------------------------------------------------
   const Piece& piece(int32_t id) const { return id == kSosPiece ? sos_piece : pieces[id]; }
@@ -288,13 +377,34 @@ struct caiman_beam {
 
   // ---- response records ---------------------------------------------------------------------------------
   void emit_header(int32_t stream, int64_t key, int kind, int64_t start, int64_t dur, int n_alt) {
-    out_i.insert(out_i.end(), {stream, (int32_t)key, kind, (int32_t)start, (int32_t)dur, n_alt});
+    auto& o = out().i;
+    o.insert(o.end(), {stream, (int32_t)key, kind, (int32_t)start, (int32_t)dur, n_alt});
   }
   void emit_alt(const int32_t* y, const int32_t* ts, const float* p, size_t n) {
-    out_i.push_back((int32_t)n);
-    out_i.insert(out_i.end(), y, y + n);
-    out_i.insert(out_i.end(), ts, ts + n);
-    out_f.insert(out_f.end(), p, p + n);
+    Out& o = out();
+    o.i.push_back((int32_t)n);
+    o.i.insert(o.i.end(), y, y + n);
+    o.i.insert(o.i.end(), ts, ts + n);
+    o.f.insert(o.f.end(), p, p + n);
+  }
+  // run fn(stream index in `list`) over a list of streams, on the worker threads when the list is long
+  template <typename F>
+  void for_streams(int64_t n, F&& fn) {
+    if (!workers || n < 128) {
+      for (int64_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    workers->run(n, 32, [&](int64_t b, int64_t e, int w) {
+      tl_out = &outs[w];
+      tl_freed = &outs[w].freed;
+      for (int64_t i = b; i < e; ++i) fn(i);
+      tl_out = nullptr;
+      tl_freed = nullptr;
+    });
+    for (auto& o : outs) {
+      pool.free_list.insert(pool.free_list.end(), o.freed.begin(), o.freed.end());
+      o.freed.clear();
+    }
   }
   // final built from hyps that share s_seq[1:tkn_idx] (serialise_responses.py:150-205); hyps[0] gives the
   // ids and confidences, the frame of each token is the earliest any hypothesis saw it
@@ -393,7 +503,8 @@ struct caiman_beam {
     const double since_final = (double)(t - s.last_final_idx) * cfg.frame_width;
     // a frame may retry the final after dropping hypotheses; only the last attempt's record is kept
     while (true) {
-      const size_t mark_i = out_i.size(), mark_f = out_f.size();
+      Out& o = out();
+      const size_t mark_i = o.i.size(), mark_f = o.f.size();
       const bool shipped = get_final(si, t, &s.kept);
       if (cfg.return_partials) emit_partials(si, t, s.kept);
       if (!shipped && !cfg.return_partials) emit_header(si, t, 2, t, 0, 0);
@@ -413,8 +524,8 @@ struct caiman_beam {
       for (size_t i = 1; i < s.kept.size(); ++i)
         if (s.kept.v[i]->norm_score() < s.kept.v[worst]->norm_score()) worst = (int)i;
       s.kept.pop(worst);
-      out_i.resize(mark_i);
-      out_f.resize(mark_f);
+      o.i.resize(mark_i);
+      o.f.resize(mark_f);
     }
     if (silence_terminate(s.kept, t)) return finish(si, t + 1);
     s.t += 1;
@@ -435,7 +546,7 @@ struct caiman_beam {
       return;
     }
     if (tok == 0) {  // id 0 is <unk>: it has no text to hash or score (beam.py:621,635)
-      saw_unk = true;
+      saw_unk.store(true);
       return;
     }
     HypPtr h(new Hyp(parent));
@@ -498,6 +609,8 @@ struct caiman_beam {
   }
 };
 
+thread_local caiman_beam::Out* caiman_beam::tl_out = nullptr;
+
 // ---- C entry points --------------------------------------------------------------------------------------
 #define BEAM_CHECK(cond, ...)             \
   do {                                    \
@@ -554,6 +667,14 @@ extern "C" caiman_beam_t* caiman_beam_create(const caiman_beam_config_t* cfg, in
   }
   h->streams.resize(n_streams);
   for (int32_t s = 0; s < n_streams; ++s) h->streams[s].kept.v.push_back(h->sos_hyp());
+  // streams are independent: long request lists are spread over worker threads (CAIMAN_BEAM_THREADS, default
+  // min(hardware threads, 16); 1 = everything on the calling thread)
+  int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = std::getenv("CAIMAN_BEAM_THREADS")) nt = std::max(1, std::atoi(e));
+  if (nt > 1 && n_streams >= 128) {
+    h->workers.reset(new Workers(nt));
+    h->outs.resize(nt);
+  }
   return h.release();
 }
 
@@ -601,9 +722,12 @@ extern "C" int64_t caiman_beam_requests(caiman_beam_t* h, int32_t* stream, int32
     caiman::set_error("beam_requests: %lld requests pending but room for %lld", (long long)live.size(), (long long)cap);
     return -1;
   }
+  h->for_streams((int64_t)live.size(), [&](int64_t i) {
+    auto& s = h->streams[live[i]];
+    s.cur = s.open.pop(s.open.argmax_score());
+  });
   for (int32_t si : live) {
     auto& s = h->streams[si];
-    s.cur = s.open.pop(s.open.argmax_score());
     s.cur_out_slot = h->pool.acquire();
     h->pending.push_back({si, (int32_t)s.t, s.cur->y.back(), s.cur->slot, s.cur_out_slot});
   }
@@ -632,9 +756,10 @@ extern "C" int caiman_beam_feed(caiman_beam_t* h, int64_t n, int32_t k, const fl
     }
   std::vector<Request> reqs;
   reqs.swap(h->pending);
-  for (int64_t i = 0; i < n; ++i)
+  h->for_streams(n, [&](int64_t i) {
     h->feed_one(reqs[i].stream, k, top_scores + i * k, top_tokens + i * k, blank_logp[i]);
-  BEAM_CHECK(!h->saw_unk, "Decoding error: '<unk>' token encountered");
+  });
+  BEAM_CHECK(!h->saw_unk.load(), "Decoding error: '<unk>' token encountered");
   return CAIMAN_OK;
 }
 
@@ -655,6 +780,12 @@ extern "C" int64_t caiman_beam_state_slots(const caiman_beam_t* h) { return h ? 
 extern "C" int caiman_beam_responses(caiman_beam_t* h, const int32_t** ints, int64_t* n_ints, const float** floats,
                                      int64_t* n_floats) {
   BEAM_CHECK(h && ints && n_ints && floats && n_floats, "beam_responses: null argument");
+  for (auto& o : h->outs) {
+    h->out_i.insert(h->out_i.end(), o.i.begin(), o.i.end());
+    h->out_f.insert(h->out_f.end(), o.f.begin(), o.f.end());
+    o.i.clear();
+    o.f.clear();
+  }
   *ints = h->out_i.data();
   *n_ints = (int64_t)h->out_i.size();
   *floats = h->out_f.data();

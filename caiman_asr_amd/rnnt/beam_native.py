@@ -12,6 +12,7 @@ fixed-shape device->host copy -> `caiman_beam_feed`.
 """
 import ctypes
 import json
+import time
 from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
@@ -142,7 +143,8 @@ class NativeBeamSearch:
                 fr.final = DecodingResponse(start, dur, False, alts)
             elif kind == 1:
                 fr.partials = DecodingResponse(start, dur, True, alts)
-        return out
+        # worker threads write records in their own buffers: restore frame order per stream
+        return [dict(sorted(d.items())) if len(d) > 1 else d for d in out]
 
 
 class HipBeamStep:
@@ -252,15 +254,29 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
             eos_terminal_idx=(eos_strategy.eos_idx if eos_is_terminal and isinstance(eos_strategy, EOSPredict) else None),
             return_partials=return_partials, keywords=kw, keyword_weights=kww)
         self.step = device_step or HipBeamStep(self.model, blank_idx, beam_width, temperature, eos_strategy)
+        self.profile: Optional[Dict[str, float]] = None   # set to a defaultdict(float) to collect host timings
 
     def _rounds(self, search: NativeBeamSearch, frame_of):
         """Expansion rounds until no stream has a request left.  `frame_of(streams, frames)` -> f [n, 1, Hj]."""
+        n_rounds = 0
+        prof = self.profile
         while True:
+            t0 = time.perf_counter()
             stream, frame, y_last, s_in, s_out = search.requests()
             if len(stream) == 0:
-                return
+                return n_rounds
+            n_rounds += 1
+            t1 = time.perf_counter()
             scores, tokens, blank = self.step(frame_of(stream, frame), y_last, s_in, s_out, search.state_slots())
+            t2 = time.perf_counter()
             search.feed(scores, tokens, blank)
+            if prof is not None:
+                t3 = time.perf_counter()
+                prof["requests"] += t1 - t0
+                prof["device_round"] += t2 - t1
+                prof["feed"] += t3 - t2
+                prof["rounds"] += 1
+                prof["expansions"] += len(stream)
 
     @torch.no_grad()
     def _inner_decode(self, encs: torch.Tensor, encs_len: torch.Tensor) -> List[Dict[int, FrameResponses]]:
@@ -301,7 +317,12 @@ class StreamingBeamDecoder:
     @torch.no_grad()
     def step(self, feats: torch.Tensor) -> List[Dict[int, FrameResponses]]:
         self.model.eval()
+        prof = self.dec.profile
+        t0 = time.perf_counter()
         f_all = self.encoder.advance(feats)
+        if prof is not None:
+            torch.cuda.synchronize()
+            prof["encoder"] += time.perf_counter() - t0
         if f_all is None:
             return [dict() for _ in range(self.B)]
         for j in range(f_all.shape[1]):
@@ -313,8 +334,12 @@ class StreamingBeamDecoder:
                 return fj.index_select(0, torch.from_numpy(stream.astype(np.int64)).to(fj.device)).unsqueeze(1)
 
             self.search.push_frame(self.all_streams)
-            self.dec._rounds(self.search, frame_of)
-        return self.search.take_responses()
+            self.rounds += self.dec._rounds(self.search, frame_of)
+        t0 = time.perf_counter()
+        out = self.search.take_responses()
+        if prof is not None:
+            prof["responses"] += time.perf_counter() - t0
+        return out
 
     def close(self) -> List[Dict[int, FrameResponses]]:
         for b in range(self.B):

@@ -262,6 +262,50 @@ def test_native_search_abi_errors():
                np.full(len(stream), -3.0, np.float32))
 
 
+def _drive_synthetic(search, n_streams, n_frames, k=4, blank=28):
+    """Answers are a pure function of the request, so two searches fed by it must agree whatever their threading."""
+    out = [dict() for _ in range(n_streams)]
+    asked = np.zeros(n_streams, np.int64)   # slot numbers depend on the threading, request counts do not
+    for t in range(n_frames):
+        search.push_frame(np.arange(n_streams))
+        while True:
+            stream, frame, y, s_in, s_out = search.requests()
+            if len(stream) == 0:
+                break
+            sc = np.empty((len(stream), k), np.float32)
+            tk = np.empty((len(stream), k), np.int32)
+            bl = np.empty(len(stream), np.float32)
+            for i in range(len(stream)):
+                asked[stream[i]] += 1
+                rng = np.random.default_rng([int(stream[i]), int(frame[i]), int(y[i]) + 1, int(asked[stream[i]])])
+                p = rng.dirichlet(np.full(6, 0.3)) * 0.98 + 0.0033
+                ids = np.concatenate([[blank], 1 + rng.choice(27, 5, replace=False)])
+                order = np.argsort(-p)[:k]
+                sc[i], tk[i], bl[i] = np.log(p[order]), ids[order], np.log(p[0])
+            search.feed(sc, tk, bl)
+        for b, r in enumerate(search.take_responses()):
+            out[b].update(r)
+    for b in range(n_streams):
+        search.close_stream(b)
+    for b, r in enumerate(search.take_responses()):
+        out[b].update(r)
+    return out
+
+
+def test_native_search_threads_agree(monkeypatch):
+    from caiman_asr_amd.rnnt.beam_native import NativeBeamSearch
+
+    n, T = 160, 6
+    results = []
+    for threads in ("1", "5"):
+        monkeypatch.setenv("CAIMAN_BEAM_THREADS", threads)
+        s = NativeBeamSearch(n, PIECES, blank_idx=28, return_partials=True, final_emission_thresh=0.12, frame_width=0.06)
+        results.append(_drive_synthetic(s, n, T))
+        assert s.state_slots() < n * 40
+    assert results[0] == results[1]
+    assert sum(len(r.final.alternatives[0].y_seq) for per in results[0] for r in per.values() if r.final) > n
+
+
 def test_beam_limits_and_errors():
     g, m = _oracle_model()
     V = int(g["n_classes"])
