@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--beam-width", type=int, default=4)
     ap.add_argument("--top1-prob", type=float, default=0.85,
                     help="beam: mean top-1 probability of softmax(logits/1.4) the synthetic logits are scaled to (0 = keep --logit-scale)")
+    ap.add_argument("--straggler-frac", type=float, default=0.01,
+                    help="beam: a tick ends once a round serves no more than this fraction of the streams; they catch up later")
+    ap.add_argument("--pred-weight", type=float, default=0.1, help="damping of the prediction network's joint projection")
     ap.add_argument("--profile-host", action="store_true", help="beam: split the tick into host / device parts")
     args = ap.parse_args()
     from caiman_asr_amd import _lib
@@ -52,10 +55,18 @@ def main():
         # random-init logits are almost constant: widen them, then place the blank bias at the quantile that
         # makes a joint evaluation emit a non-blank with probability `emit_rate` (3.3 tokens/s over 16.7
         # encoder frames/s is ~0.2 for read speech)
+        # With random weights and widened logits the prediction network's contribution swamps the acoustic one and
+        # decoding turns bistable (all blank, or runaway emission after the first token).  A trained transducer's
+        # decisions are mostly acoustic: damp the prediction projection so that the emission rate is controllable.
+        model.joint_pred.weight.mul_(args.pred_weight)
+        model.joint_pred.bias.mul_(args.pred_weight)
         probe = torch.randn(40, 256, 240, device=dev)
         f, _, _ = model.encode(probe, torch.full((256,), 40, device=dev))
-        g, _, _ = model.predict(None, None, add_sos=False)
-        raw = model.joint(f[:, -4:].reshape(-1, 1, f.shape[-1]), g.expand(f.shape[0] * 4, -1, -1))[:, 0, 0].float()
+        # prediction-network outputs after random token histories (the search visits many of them), SOS included
+        hist = torch.randint(1, N_CLASSES - 1, (256, 7), device=dev)
+        g, _, _ = model.predict(hist, None, add_sos=True)                      # [256, 8, Hj]
+        g = g.reshape(-1, 1, g.shape[-1])[torch.randperm(256 * 8, device=dev)[:1024]]
+        raw = model.joint(f[:, -4:].reshape(-1, 1, f.shape[-1]), g)[:, 0, 0].float()
         raw[:, 0] = -1e4 if args.decoder == "beam" else raw[:, 0]
 
         def blank_shift(scale):   # bias that makes P(argmax != blank) = emit_rate at this scale
@@ -64,34 +75,107 @@ def main():
 
         scale = args.logit_scale
         if args.decoder == "beam" and args.top1_prob > 0:
-            # a trained transducer is confident: pick the scale at which the mean top-1 probability of
-            # softmax(logits / 1.4) is `top1_prob` (bisection; the blank bias is re-fitted at every scale)
-            lo, hi = 1.0, 4096.0
-            for _ in range(30):
+            # a trained transducer is confident: first guess of the scale at which the mean top-1 probability of
+            # softmax(logits / 1.4) is `top1_prob` (bisection on the probe; refined closed-loop below)
+            lo, hi = 1.0, 1e7
+            for _ in range(40):
                 scale = (lo * hi) ** 0.5
                 z = scale * raw
                 z[:, -1] += blank_shift(scale)
                 top1 = torch.softmax(z / 1.4, -1).max(-1).values.mean().item()
                 lo, hi = (scale, hi) if top1 < args.top1_prob else (lo, scale)
-        model.joint_net[2].weight.mul_(scale)
-        model.joint_net[2].bias.mul_(scale)
-        model.joint_net[2].bias[N_CLASSES - 1] += blank_shift(scale)
+        W0, B0 = model.joint_net[2].weight.detach().clone(), model.joint_net[2].bias.detach().clone()
+
+        def set_scale(sc, blank_bias):
+            model.joint_net[2].weight.copy_(W0 * sc)
+            model.joint_net[2].bias.copy_(B0 * sc)
+            model.joint_net[2].bias[N_CLASSES - 1] += blank_bias
+            if args.decoder == "beam":   # id 0 is <unk>: the search refuses it, a trained model never emits it
+                model.joint_net[2].weight[0].zero_()
+                model.joint_net[2].bias[0] = -1e4
+
+        set_scale(scale, blank_shift(scale))
     if args.decoder == "beam":
         from caiman_asr_amd.rnnt.beam_native import StreamingBeamDecoder
 
-        with torch.no_grad():   # id 0 is <unk>: the search refuses it, a trained model never emits it
-            model.joint_net[2].weight[0].zero_()
-            model.joint_net[2].bias[0] = -1e4
         # synthetic vocabulary: unique lower-case strings, every third one starts a word
         letters = "abcdefghijklmnopqrstuvwxyz"
         pieces = ["<unk>"] + [("\u2581" if i % 3 == 0 else "") + "".join(letters[(i // 26 ** d) % 26] for d in range(3))
                               for i in range(1, N_CLASSES - 1)]
-        dec = StreamingBeamDecoder(model, N_CLASSES - 1, args.streams, pieces, beam_width=args.beam_width,
-                                   max_symbols_per_step=args.max_symbols, temperature=1.4)
+
+        def new_decoder(n, cutoff=0):
+            return StreamingBeamDecoder(model, N_CLASSES - 1, n, pieces, beam_width=args.beam_width,
+                                        max_symbols_per_step=args.max_symbols, temperature=1.4, straggler_cutoff=cutoff)
+
+        # The probe cannot know which encoder / prediction states a live search visits, so both knobs are finished
+        # off closed-loop.  Blank bias: the (cheap, device-only) greedy decoder must emit `emit_rate` tokens per
+        # frame once the encoder state has settled.  Scale: approached from the confident (cheap) side until a
+        # short beam decode shows the target mean top-1 probability.
+        def greedy_rate(n=256, ticks=40, settle=20):
+            d = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=n, max_symbols_per_step=args.max_symbols)
+            gen = torch.Generator(device=dev).manual_seed(1)
+            tok = frames = 0
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                for i in range(ticks):
+                    for _, n_emit in d.step(torch.randn(2, n, 240, device=dev, generator=gen)):
+                        if i >= settle:
+                            tok += int(n_emit.sum().item())
+                            frames += n
+            return tok / max(frames, 1)
+
+        def fit_blank_bias(sc):
+            def rate(b):
+                with torch.no_grad():
+                    set_scale(sc, b)
+                return greedy_rate()
+
+            b, step = blank_shift(sc), max(1.0, 0.25 * sc * float(raw[:, 1:-1].std()))
+            lo = hi = b
+            for _ in range(24):                       # bracket: rate(lo) > target >= rate(hi)
+                if rate(hi) <= args.emit_rate:
+                    break
+                hi += step
+            for _ in range(24):
+                if rate(lo) > args.emit_rate:
+                    break
+                lo -= step
+                step *= 1.5
+            for _ in range(10):
+                mid = 0.5 * (lo + hi)
+                lo, hi = (mid, hi) if rate(mid) > args.emit_rate else (lo, mid)
+            with torch.no_grad():
+                set_scale(sc, hi)
+            return hi
+
+        def beam_stats(n=64, ticks=24, settle=12):
+            import collections
+
+            d = new_decoder(n)
+            gen = torch.Generator(device=dev).manual_seed(2)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                for i in range(ticks):
+                    if i == settle:
+                        d.dec.profile, d.dec.step.stats = collections.defaultdict(float), [0.0, 0]
+                    d.step(torch.randn(2, n, 240, device=dev, generator=gen))
+            return d.dec.step.stats[0] / max(d.dec.step.stats[1], 1), d.dec.profile["expansions"] / (n * (ticks - settle))
+
+        if args.top1_prob > 0:
+            scale *= 16.0
+            for _ in range(8):
+                bias = fit_blank_bias(scale)
+                top1, exp_per_frame = beam_stats()
+                print(f"[bench_decode] scale {scale:.1f} blank bias {bias:.2f}: greedy rate {greedy_rate():.3f}, beam top-1 "
+                      f"{top1:.3f}, expansions/stream-frame {exp_per_frame:.2f}", file=sys.stderr)
+                if top1 <= args.top1_prob + 0.02:
+                    break
+                scale /= 1.6
+        else:
+            fit_blank_bias(scale)
+        dec = new_decoder(args.streams, cutoff=int(args.straggler_frac * args.streams))
     else:
         dec = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=args.streams, max_symbols_per_step=args.max_symbols)
     feats = [torch.randn(2, args.streams, 240, device=dev) for _ in range(8)]
-    lat, tokens, frames = [], 0, 0
+    lat, tokens, frames, lags = [], 0, 0, []
     with torch.autocast("cuda", dtype=torch.bfloat16):
         for i in range(args.warmup + args.ticks):
             torch.cuda.synchronize()
@@ -109,6 +193,9 @@ def main():
                 import collections
 
                 dec.dec.profile = collections.defaultdict(float)
+                dec.dec.step.stats = [0.0, 0]
+            if args.decoder == "beam" and i >= args.warmup:
+                lags.append(dec.backlog())
             if i >= args.warmup:
                 lat.append(dt)
                 tokens += n_tok
@@ -122,7 +209,11 @@ def main():
         "metric": f"real-time streams per GPU (streaming {args.decoder} decode, base RNN-T)", "streams": args.streams,
         **({"beam_width": args.beam_width, "temperature": 1.4,
             "expansion_rounds_per_tick": dec.rounds / max(args.warmup + args.ticks, 1),
-            "synthetic_top1_prob": args.top1_prob, "logit_scale": scale} if args.decoder == "beam" else {}),
+            "straggler_frac": args.straggler_frac, "max_stream_lag_frames": max(lags), "mean_max_lag_frames": sum(lags) / len(lags),
+            "synthetic_top1_prob_target": args.top1_prob, "logit_scale": scale,
+            **({"measured_mean_top1_prob": dec.dec.step.stats[0] / max(dec.dec.step.stats[1], 1),
+                "expansions_per_stream_frame": dec.dec.profile["expansions"] / (args.ticks * args.streams)}
+               if args.profile_host else {})} if args.decoder == "beam" else {}),
         "tick_audio_ms": 60.0, "tick_latency_ms": {"p50": p50 * 1e3, "p99": p99 * 1e3, "max": worst * 1e3},
         "real_time": bool(p99 < 0.060), "rtf_p99": p99 / 0.060,
         "max_streams_at_p99_linear_estimate": int(args.streams * 0.060 / p99),

@@ -139,6 +139,7 @@ _SIGS = {
     "caiman_beam_close_stream": ([P, I32], ctypes.c_int),
     "caiman_beam_stream_done": ([P, I32], ctypes.c_int),
     "caiman_beam_state_slots": ([P], ctypes.c_int64),
+    "caiman_beam_backlog": ([P, I32], ctypes.c_int64),
     "caiman_beam_responses": ([P, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.POINTER(ctypes.c_int64),
                                ctypes.POINTER(ctypes.POINTER(ctypes.c_float)), ctypes.POINTER(ctypes.c_int64)],
                               ctypes.c_int),

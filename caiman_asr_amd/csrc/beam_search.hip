@@ -311,7 +311,8 @@ struct caiman_beam {
     HypSet kept, open, closed;
     HypPtr cur;
     int32_t cur_out_slot = -1;
-    int64_t t = 0;
+    int64_t t = 0;      // frames finished
+    int64_t avail = 0;  // frames pushed
     int64_t last_final_idx = 0;
     bool frame_open = false;
     bool done = false;
@@ -467,7 +468,8 @@ struct caiman_beam {
     s.open.clear();
     s.closed.clear();
   }
-  void open_frame(int32_t si) {
+  // starts the expansion of frame s.t (does not touch the live list: safe on a worker thread)
+  void begin_frame(int32_t si) {
     Stream& s = streams[si];
     if (cfg.max_symbol_per_sample >= 0) {
       const Hyp& best = *s.kept.v[s.kept.argmax_score()];
@@ -478,7 +480,6 @@ struct caiman_beam {
     s.kept.v.clear();
     s.closed.clear();
     s.frame_open = true;
-    live.push_back(si);
   }
   bool silence_terminate(const HypSet& kept, int64_t idx) const {  // beam.py:266-283
     if (cfg.eos_vad_threshold == kInf) return false;
@@ -529,6 +530,7 @@ struct caiman_beam {
     }
     if (silence_terminate(s.kept, t)) return finish(si, t + 1);
     s.t += 1;
+    if (s.t < s.avail) begin_frame(si);  // a queued frame: the stream stays in the live list
   }
 
   void update_hyps(Stream& s, float logp_f, int32_t tok, int64_t time_idx, int32_t out_slot) {  // beam.py:449-516
@@ -696,12 +698,18 @@ extern "C" int caiman_beam_push_frame(caiman_beam_t* h, const int32_t* streams, 
   for (int32_t i = 0; i < n; ++i) {
     const int32_t si = streams[i];
     BEAM_CHECK(si >= 0 && si < (int32_t)h->streams.size(), "beam_push_frame: stream %d out of range", si);
-    BEAM_CHECK(!h->streams[si].frame_open, "beam_push_frame: stream %d still has an open frame", si);
   }
   auto& live = h->live;
   live.erase(std::remove_if(live.begin(), live.end(), [&](int32_t si) { return !h->streams[si].frame_open; }), live.end());
-  for (int32_t i = 0; i < n; ++i)
-    if (!h->streams[streams[i]].done) h->open_frame(streams[i]);
+  for (int32_t i = 0; i < n; ++i) {
+    auto& s = h->streams[streams[i]];
+    if (s.done) continue;
+    s.avail += 1;
+    if (!s.frame_open) {  // idle: start on the new frame now; otherwise it waits its turn
+      h->begin_frame(streams[i]);
+      if (s.frame_open) live.push_back(streams[i]);
+    }
+  }
   return CAIMAN_OK;
 }
 
@@ -766,13 +774,22 @@ extern "C" int caiman_beam_feed(caiman_beam_t* h, int64_t n, int32_t k, const fl
 extern "C" int caiman_beam_close_stream(caiman_beam_t* h, int32_t stream) {
   BEAM_CHECK(h && stream >= 0 && stream < (int32_t)h->streams.size(), "beam_close_stream: bad handle / stream %d", stream);
   auto& s = h->streams[stream];
-  BEAM_CHECK(!s.frame_open, "beam_close_stream: stream %d still has an open frame", stream);
+  BEAM_CHECK(!s.frame_open, "beam_close_stream: stream %d still has frames to expand", stream);
   if (!s.done) h->finish(stream, s.t);
   return CAIMAN_OK;
 }
 
 extern "C" int caiman_beam_stream_done(const caiman_beam_t* h, int32_t stream) {
   return h && stream >= 0 && stream < (int32_t)h->streams.size() && h->streams[stream].done ? 1 : 0;
+}
+
+extern "C" int64_t caiman_beam_backlog(const caiman_beam_t* h, int32_t stream) {
+  if (!h) return 0;
+  auto lag = [](const caiman_beam::Stream& s) { return s.done ? (int64_t)0 : s.avail - s.t; };
+  if (stream >= 0) return stream < (int32_t)h->streams.size() ? lag(h->streams[stream]) : 0;
+  int64_t m = 0;
+  for (auto& s : h->streams) m = std::max(m, lag(s));
+  return m;
 }
 
 extern "C" int64_t caiman_beam_state_slots(const caiman_beam_t* h) { return h ? (int64_t)h->pool.refs.size() : 0; }

@@ -113,6 +113,10 @@ class NativeBeamSearch:
     def done(self, i: int) -> bool:
         return bool(self.L.caiman_beam_stream_done(self.h, i))
 
+    def backlog(self, stream: int = -1) -> int:
+        """Frames pushed but not finished on `stream` (-1: the maximum over all streams)."""
+        return int(self.L.caiman_beam_backlog(self.h, stream))
+
     def state_slots(self) -> int:
         return int(self.L.caiman_beam_state_slots(self.h))
 
@@ -165,6 +169,7 @@ class HipBeamStep:
             self.eos = (3, eos_strategy.eos_idx, float(eos_strategy.alpha), float(eos_strategy.beta))
         self.h_pool = self.c_pool = None
         self.host = None
+        self.stats = None
 
     def _ensure(self, n_slots: int, n: int, dev, dtype):
         m = self.model
@@ -215,6 +220,9 @@ class HipBeamStep:
         hflat[: 2 * n * k + n].copy_(flat[: 2 * n * k + n], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         hn = hflat.numpy()
+        if self.stats is not None:   # [sum of top-1 probabilities, rows]: how peaked the workload is
+            self.stats[0] += float(np.exp(hn[: n * k: k]).sum())
+            self.stats[1] += n
         return (hn[: n * k].reshape(n, k), hn[n * k: 2 * n * k].view(np.int32).reshape(n, k), hn[2 * n * k: 2 * n * k + n])
 
 
@@ -256,8 +264,10 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
         self.step = device_step or HipBeamStep(self.model, blank_idx, beam_width, temperature, eos_strategy)
         self.profile: Optional[Dict[str, float]] = None   # set to a defaultdict(float) to collect host timings
 
-    def _rounds(self, search: NativeBeamSearch, frame_of):
-        """Expansion rounds until no stream has a request left.  `frame_of(streams, frames)` -> f [n, 1, Hj]."""
+    def _rounds(self, search: NativeBeamSearch, frame_of, stop_below: int = 0):
+        """Expansion rounds until no stream has a request left -- or, with `stop_below`, until a round served no
+        more than that many streams (the stragglers carry on in the next call).  `frame_of(streams, frames)` ->
+        f [n, 1, Hj]."""
         n_rounds = 0
         prof = self.profile
         while True:
@@ -277,6 +287,8 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
                 prof["feed"] += t3 - t2
                 prof["rounds"] += 1
                 prof["expansions"] += len(stream)
+            if len(stream) <= stop_below:
+                return n_rounds
 
     @torch.no_grad()
     def _inner_decode(self, encs: torch.Tensor, encs_len: torch.Tensor) -> List[Dict[int, FrameResponses]]:
@@ -303,16 +315,35 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
 class StreamingBeamDecoder:
     """N live streams: `step(feats)` takes the next chunk of spliced features for all streams ([frames, N, in_feats];
     2 frames = 60 ms at the base config), advances the encoder with its carried state and runs the beam search over
-    the encoder frames the chunk completes.  Returns the responses produced by the chunk."""
+    the encoder frames the chunk completes.  Returns the responses produced during the call.
 
-    def __init__(self, model, blank_idx: int, n_streams: int, sentpiece_model: Union[str, Sequence[str]], **kwargs):
+    A frame on which a stream's beam is slow to settle can need a hundred expansions while the typical one needs
+    a handful; waiting for it would make every stream late.  With `straggler_cutoff` > 0 a tick ends once a round
+    served no more than that many streams: those streams keep their open frame, queue the frames that arrive
+    meanwhile (`ring` encoder frames are kept) and catch up inside later ticks.  `backlog()` reports the lag."""
+
+    def __init__(self, model, blank_idx: int, n_streams: int, sentpiece_model: Union[str, Sequence[str]],
+                 straggler_cutoff: int = 0, ring: int = 32, **kwargs):
         self.dec = RNNTBeamDecoderNative(model, blank_idx, kwargs.pop("eos_strategy", None), sentpiece_model, **kwargs)
         self.model = self.dec.model
         self.B = n_streams
         self.encoder = StreamingEncoder(self.model, n_streams)
         self.search = NativeBeamSearch(n_streams, **self.dec.search_args)
         self.all_streams = np.arange(n_streams, dtype=np.int32)
+        self.straggler_cutoff, self.ring = straggler_cutoff, ring
+        self.frames = None        # [ring, N, Hj] the most recent encoder frames
+        self.n_frames = 0
         self.rounds = 0
+
+    def backlog(self) -> int:
+        return self.search.backlog(-1)
+
+    def _frame_of(self, stream, frame):
+        if len(stream) == self.B and int(frame[0]) == int(frame[-1]) == self.n_frames - 1:
+            return self.frames[(self.n_frames - 1) % self.ring].unsqueeze(1)   # everyone on the newest frame, in order
+        dev = self.frames.device
+        idx = torch.from_numpy(np.stack([frame % self.ring, stream]).astype(np.int64)).to(dev, non_blocking=True)
+        return self.frames[idx[0], idx[1]].unsqueeze(1)
 
     @torch.no_grad()
     def step(self, feats: torch.Tensor) -> List[Dict[int, FrameResponses]]:
@@ -325,16 +356,15 @@ class StreamingBeamDecoder:
             prof["encoder"] += time.perf_counter() - t0
         if f_all is None:
             return [dict() for _ in range(self.B)]
+        if self.frames is None:
+            self.frames = torch.zeros(self.ring, self.B, f_all.shape[-1], device=f_all.device, dtype=f_all.dtype)
         for j in range(f_all.shape[1]):
-            fj = f_all[:, j]
-
-            def frame_of(stream, frame, fj=fj):
-                if len(stream) == self.B:
-                    return fj.unsqueeze(1)   # first round of a frame: every stream, already in order
-                return fj.index_select(0, torch.from_numpy(stream.astype(np.int64)).to(fj.device)).unsqueeze(1)
-
+            # the slot about to be overwritten must not be needed any more
+            cutoff = self.straggler_cutoff if self.search.backlog(-1) < self.ring - 2 else 0
+            self.frames[self.n_frames % self.ring] = f_all[:, j]
+            self.n_frames += 1
             self.search.push_frame(self.all_streams)
-            self.rounds += self.dec._rounds(self.search, frame_of)
+            self.rounds += self.dec._rounds(self.search, self._frame_of, stop_below=cutoff)
         t0 = time.perf_counter()
         out = self.search.take_responses()
         if prof is not None:
@@ -342,6 +372,7 @@ class StreamingBeamDecoder:
         return out
 
     def close(self) -> List[Dict[int, FrameResponses]]:
+        self.rounds += self.dec._rounds(self.search, self._frame_of)   # let the stragglers finish
         for b in range(self.B):
             self.search.close_stream(b)
         return self.search.take_responses()

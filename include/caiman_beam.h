@@ -81,11 +81,15 @@ void caiman_beam_destroy(caiman_beam_t* h);
 
 /* Start a new utterance on `stream` (drops its beam, frees its state slots). */
 int caiman_beam_reset_stream(caiman_beam_t* h, int32_t stream);
-/* The next encoder frame of each listed stream is available: opens that frame's expansion.  Streams that
- * have ended (terminal token, silence, symbol budget) ignore it.  A stream must have no open frame. */
+/* The next encoder frame of each listed stream is available.  An idle stream starts expanding it at once; a
+ * stream still busy with an earlier frame queues it and moves on by itself when that frame closes, so a few
+ * slow streams need not hold up a real-time tick (the caller keeps the encoder frames it has pushed until
+ * caiman_beam_backlog says they are done).  Streams that have ended (terminal token, silence, symbol budget)
+ * ignore the call. */
 int caiman_beam_push_frame(caiman_beam_t* h, const int32_t* streams, int32_t n);
 /* Pending expansions, one per stream with an open frame.  y_last = -1 and state_in = -1 mark the
- * start-of-sequence step (zero embedding, zero state).  state_out is a fresh slot the caller must fill
+ * start-of-sequence step (zero embedding, zero state).  `frame` is the index (count of frames pushed before it)
+ * of the encoder frame the hypothesis is to be expanded on.  state_out is a fresh slot the caller must fill
  * with the new prediction state.  Returns the count (<= cap), or -1 on error. */
 int64_t caiman_beam_requests(caiman_beam_t* h, int32_t* stream, int32_t* frame, int32_t* y_last,
                              int32_t* state_in, int32_t* state_out, int64_t cap);
@@ -97,6 +101,8 @@ int caiman_beam_feed(caiman_beam_t* h, int64_t n, int32_t k, const float* top_sc
 int caiman_beam_close_stream(caiman_beam_t* h, int32_t stream);
 /* 1 if the stream has ended by itself or was closed. */
 int caiman_beam_stream_done(const caiman_beam_t* h, int32_t stream);
+/* Frames pushed but not yet finished on `stream`; stream = -1: the maximum over all streams. */
+int64_t caiman_beam_backlog(const caiman_beam_t* h, int32_t stream);
 /* Number of state slots the device pool must hold (grows; check after caiman_beam_requests). */
 int64_t caiman_beam_state_slots(const caiman_beam_t* h);
 

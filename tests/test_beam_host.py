@@ -244,8 +244,10 @@ def test_native_search_abi_errors():
         NativeBeamSearch(2, PIECES, blank_idx=28, keywords=["ab", "ab"], keyword_weights=[1.0, 2.0])
     s = NativeBeamSearch(2, PIECES, blank_idx=28)
     s.push_frame(np.array([0, 1]))
-    with pytest.raises(RuntimeError, match="open frame"):
-        s.push_frame(np.array([0]))
+    s.push_frame(np.array([0]))                        # queued behind the frame stream 0 is busy with
+    assert (s.backlog(0), s.backlog(1), s.backlog()) == (2, 1, 2)
+    with pytest.raises(RuntimeError, match="frames to expand"):
+        s.close_stream(0)
     stream, frame, y, s_in, s_out = s.requests()
     assert stream.tolist() == [0, 1] and frame.tolist() == [0, 0] and y.tolist() == [-1, -1] and s_in.tolist() == [-1, -1]
     assert s_out.tolist() == [0, 1] and s.state_slots() == 2
@@ -262,12 +264,18 @@ def test_native_search_abi_errors():
                np.full(len(stream), -3.0, np.float32))
 
 
-def _drive_synthetic(search, n_streams, n_frames, k=4, blank=28):
-    """Answers are a pure function of the request, so two searches fed by it must agree whatever their threading."""
+def _drive_synthetic(search, n_streams, n_frames, k=4, blank=28, queue_all=False):
+    """Answers are a pure function of the request, so two searches fed by it must agree whatever their threading
+    -- and whether frames are pushed one at a time or queued ahead of the search."""
     out = [dict() for _ in range(n_streams)]
     asked = np.zeros(n_streams, np.int64)   # slot numbers depend on the threading, request counts do not
-    for t in range(n_frames):
-        search.push_frame(np.arange(n_streams))
+    if queue_all:
+        for t in range(n_frames):
+            search.push_frame(np.arange(n_streams))
+        assert search.backlog() == n_frames
+    for t in range(1 if queue_all else n_frames):
+        if not queue_all:
+            search.push_frame(np.arange(n_streams))
         while True:
             stream, frame, y, s_in, s_out = search.requests()
             if len(stream) == 0:
@@ -303,6 +311,8 @@ def test_native_search_threads_agree(monkeypatch):
         results.append(_drive_synthetic(s, n, T))
         assert s.state_slots() < n * 40
     assert results[0] == results[1]
+    s = NativeBeamSearch(n, PIECES, blank_idx=28, return_partials=True, final_emission_thresh=0.12, frame_width=0.06)
+    assert _drive_synthetic(s, n, T, queue_all=True) == results[0] and s.backlog() == 0
     assert sum(len(r.final.alternatives[0].y_seq) for per in results[0] for r in per.values() if r.final) > n
 
 

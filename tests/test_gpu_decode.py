@@ -220,3 +220,37 @@ def test_streaming_beam_equals_offline():
     for a, b in zip(cf_s, cf_o):                 # batch shapes differ between the two runs: GEMM rounding only
         assert np.allclose(a, b, atol=1e-4)
     assert [sorted(r) for r in merged] == [sorted(r) for r in off]
+
+
+def test_streaming_beam_stragglers_catch_up():
+    """Ending ticks early (slow streams keep their frame and queue the new ones) changes when responses appear,
+    not what they are."""
+    from caiman_asr_amd.rnnt.beam_native import StreamingBeamDecoder
+    from caiman_asr_amd.rnnt.decoder import flatten_responses
+    from tests.test_beam_host import BEAM, PIECES
+
+    g, m = build("mfma")
+    with torch.no_grad():
+        m.joint_fc.bias[0] = BEAM["unk_bias"]
+    V = int(g["n_classes"])
+    torch.manual_seed(7)
+    T, B = 32, 12
+    x = torch.randn(T, B, g["x"].shape[2], device=DEV)
+    results, lagged = [], 0
+    for cutoff in (0, 6):
+        dec = StreamingBeamDecoder(m, V - 1, B, PIECES, straggler_cutoff=cutoff, ring=8)
+        merged = [dict() for _ in range(B)]
+        for t0 in range(0, T, 2):
+            for b, r in enumerate(dec.step(x[t0:t0 + 2])):
+                merged[b].update(r)
+            lagged += dec.backlog() if cutoff else 0
+        for b, r in enumerate(dec.close()):
+            merged[b].update(r)
+        assert dec.backlog() == 0
+        results.append((flatten_responses(merged), [sorted(r) for r in merged]))
+    (tk0, ts0, cf0), keys0 = results[0]
+    (tk1, ts1, cf1), keys1 = results[1]
+    assert lagged > 0, "the cutoff never left a straggler: the test does not exercise the queue"
+    assert tk0 == tk1 and ts0 == ts1 and keys0 == keys1
+    for a, b in zip(cf0, cf1):
+        assert np.allclose(a, b, atol=1e-4)
