@@ -39,6 +39,8 @@ def main():
                     help="beam: mean top-1 probability of softmax(logits/1.4) the synthetic logits are scaled to (0 = keep --logit-scale)")
     ap.add_argument("--straggler-frac", type=float, default=0.01,
                     help="beam: a tick ends once a round serves no more than this fraction of the streams; they catch up later")
+    ap.add_argument("--max-expansions", type=int, default=64,
+                    help="beam: serving safeguard, settle a frame after this many expansions of one stream (0 = off)")
     ap.add_argument("--pred-weight", type=float, default=0.1, help="damping of the prediction network's joint projection")
     ap.add_argument("--profile-host", action="store_true", help="beam: split the tick into host / device parts")
     args = ap.parse_args()
@@ -105,7 +107,8 @@ def main():
 
         def new_decoder(n, cutoff=0):
             return StreamingBeamDecoder(model, N_CLASSES - 1, n, pieces, beam_width=args.beam_width,
-                                        max_symbols_per_step=args.max_symbols, temperature=1.4, straggler_cutoff=cutoff)
+                                        max_symbols_per_step=args.max_symbols, temperature=1.4, straggler_cutoff=cutoff,
+                                        max_expansions_per_frame=args.max_expansions)
 
         # The probe cannot know which encoder / prediction states a live search visits, so both knobs are finished
         # off closed-loop.  Blank bias: the (cheap, device-only) greedy decoder must emit `emit_rate` tokens per
@@ -209,12 +212,16 @@ def main():
         "metric": f"real-time streams per GPU (streaming {args.decoder} decode, base RNN-T)", "streams": args.streams,
         **({"beam_width": args.beam_width, "temperature": 1.4,
             "expansion_rounds_per_tick": dec.rounds / max(args.warmup + args.ticks, 1),
+            "max_expansions_per_frame": args.max_expansions,
+            "frames_settled_by_cap_frac": dec.search.capped_frames() / max(dec.n_frames * args.streams, 1),
             "straggler_frac": args.straggler_frac, "max_stream_lag_frames": max(lags), "mean_max_lag_frames": sum(lags) / len(lags),
             "synthetic_top1_prob_target": args.top1_prob, "logit_scale": scale,
             **({"measured_mean_top1_prob": dec.dec.step.stats[0] / max(dec.dec.step.stats[1], 1),
                 "expansions_per_stream_frame": dec.dec.profile["expansions"] / (args.ticks * args.streams)}
                if args.profile_host else {})} if args.decoder == "beam" else {}),
         "tick_audio_ms": 60.0, "tick_latency_ms": {"p50": p50 * 1e3, "p99": p99 * 1e3, "max": worst * 1e3},
+        "ticks": len(lat), "ticks_over_60ms": sum(1 for x in lat if x > 0.060),
+        "slowest_ticks_ms": [round(x * 1e3, 1) for x in lat[-5:]],
         "real_time": bool(p99 < 0.060), "rtf_p99": p99 / 0.060,
         "max_streams_at_p99_linear_estimate": int(args.streams * 0.060 / p99),
         "tokens_per_encoder_frame": tokens / max(frames, 1), "dtype": "bf16", "data": "synthetic",

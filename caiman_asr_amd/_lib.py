@@ -91,7 +91,7 @@ class BeamConfig(ctypes.Structure):
                 ("beam_prune_score_thresh", ctypes.c_double), ("beam_prune_topk_thresh", ctypes.c_double),
                 ("eos_vad_threshold", ctypes.c_double), ("final_emission_thresh", ctypes.c_double),
                 ("frame_width", ctypes.c_double), ("eos_terminal_idx", ctypes.c_int32),
-                ("return_partials", ctypes.c_int32)]
+                ("return_partials", ctypes.c_int32), ("max_expansions_per_frame", ctypes.c_int32)]
 
 
 P = ctypes.c_void_p
@@ -129,6 +129,9 @@ _SIGS = {
     "caiman_lstm_fused_bwd": ([P, P, P, P, I64, I64, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     # include/caiman_beam.h
     "caiman_beam_topk": ([P, I64, I64, I64, I32, F32, I32, I32, I32, F32, F32, I32, P, P, P, P], ctypes.c_int),
+    "caiman_beam_gather_inputs": ([P, I64, P, I64, P, P, I64, P, I64, I32, P], ctypes.c_int),
+    "caiman_beam_lstm_cell": ([P, I64, P, P, P, P, P, I64, P, I64, I32, P], ctypes.c_int),
+    "caiman_beam_joint_act": ([P, P, P, I64, I64, P, I32, P], ctypes.c_int),
     "caiman_beam_create": ([ctypes.POINTER(BeamConfig), I32, ctypes.POINTER(ctypes.c_char_p), I32,
                             ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), I32], ctypes.c_void_p),
     "caiman_beam_destroy": ([P], None),
@@ -140,6 +143,7 @@ _SIGS = {
     "caiman_beam_stream_done": ([P, I32], ctypes.c_int),
     "caiman_beam_state_slots": ([P], ctypes.c_int64),
     "caiman_beam_backlog": ([P, I32], ctypes.c_int64),
+    "caiman_beam_capped_frames": ([P], ctypes.c_int64),
     "caiman_beam_responses": ([P, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.POINTER(ctypes.c_int64),
                                ctypes.POINTER(ctypes.POINTER(ctypes.c_float)), ctypes.POINTER(ctypes.c_int64)],
                               ctypes.c_int),

@@ -312,6 +312,7 @@ struct caiman_beam {
     HypPtr cur;
     int32_t cur_out_slot = -1;
     int64_t t = 0;      // frames finished
+    int32_t expansions = 0;  // of the open frame
     int64_t avail = 0;  // frames pushed
     int64_t last_final_idx = 0;
     bool frame_open = false;
@@ -331,6 +332,7 @@ struct caiman_beam {
   std::vector<int32_t> out_i;
   std::vector<float> out_f;
   std::atomic<bool> saw_unk{false};
+  std::atomic<int64_t> capped_frames{0};
   std::unique_ptr<Workers> workers;
   Out& out() { return tl_out ? *tl_out : outs[0]; }
 
@@ -480,6 +482,7 @@ struct caiman_beam {
     s.kept.v.clear();
     s.closed.clear();
     s.frame_open = true;
+    s.expansions = 0;
   }
   bool silence_terminate(const HypSet& kept, int64_t idx) const {  // beam.py:266-283
     if (cfg.eos_vad_threshold == kInf) return false;
@@ -597,7 +600,10 @@ struct caiman_beam {
     s.cur.reset();
     pool.release(s.cur_out_slot);  // the children hold their own references now
     s.cur_out_slot = -1;
-    if (!s.open.empty()) {
+    s.expansions += 1;
+    const bool capped = cfg.max_expansions_per_frame > 0 && s.expansions >= cfg.max_expansions_per_frame && !s.open.empty();
+    if (capped) capped_frames.fetch_add(1);  // serving safeguard: settle the frame with what has been closed so far
+    if (!s.open.empty() && !capped) {
       const double bar = s.open.v[s.open.argmax_score()]->score;
       size_t ahead = 0;
       for (auto& h : s.closed.v) ahead += h->score > bar;
@@ -791,6 +797,8 @@ extern "C" int64_t caiman_beam_backlog(const caiman_beam_t* h, int32_t stream) {
   for (auto& s : h->streams) m = std::max(m, lag(s));
   return m;
 }
+
+extern "C" int64_t caiman_beam_capped_frames(const caiman_beam_t* h) { return h ? h->capped_frames.load() : 0; }
 
 extern "C" int64_t caiman_beam_state_slots(const caiman_beam_t* h) { return h ? (int64_t)h->pool.refs.size() : 0; }
 

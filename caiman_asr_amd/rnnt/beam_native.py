@@ -54,7 +54,8 @@ class NativeBeamSearch:
                  beam_prune_score_thresh: float = 0.4, beam_prune_topk_thresh: float = 1.5,
                  eos_vad_threshold: float = INF, final_emission_thresh: float = INF,
                  frame_width: Optional[float] = None, eos_terminal_idx: Optional[int] = None,
-                 return_partials: bool = False, keywords: Sequence[str] = (), keyword_weights: Sequence[float] = ()):
+                 return_partials: bool = False, keywords: Sequence[str] = (), keyword_weights: Sequence[float] = (),
+                 max_expansions_per_frame: int = 0):
         self.L = _lib.lib()
         self.n_streams, self.k = n_streams, beam_width
         cfg = _lib.BeamConfig(
@@ -64,7 +65,8 @@ class NativeBeamSearch:
             eos_vad_threshold=-1.0 if eos_vad_threshold == INF else eos_vad_threshold,
             final_emission_thresh=-1.0 if final_emission_thresh == INF else final_emission_thresh,
             frame_width=0.0 if frame_width is None else frame_width,
-            eos_terminal_idx=-1 if eos_terminal_idx is None else eos_terminal_idx, return_partials=int(return_partials))
+            eos_terminal_idx=-1 if eos_terminal_idx is None else eos_terminal_idx, return_partials=int(return_partials),
+            max_expansions_per_frame=max_expansions_per_frame)
         pc = (ctypes.c_char_p * len(pieces))(*[p.encode("utf-8") for p in pieces])
         kw = (ctypes.c_char_p * max(len(keywords), 1))(*[k.encode("utf-8") for k in keywords])
         kww = (ctypes.c_double * max(len(keywords), 1))(*keyword_weights)
@@ -117,6 +119,10 @@ class NativeBeamSearch:
         """Frames pushed but not finished on `stream` (-1: the maximum over all streams)."""
         return int(self.L.caiman_beam_backlog(self.h, stream))
 
+    def capped_frames(self) -> int:
+        """Frames settled early by `max_expansions_per_frame`."""
+        return int(self.L.caiman_beam_capped_frames(self.h))
+
     def state_slots(self) -> int:
         return int(self.L.caiman_beam_state_slots(self.h))
 
@@ -152,13 +158,16 @@ class NativeBeamSearch:
 
 
 class HipBeamStep:
-    """One expansion round on the device.  Prediction states of all live hypotheses sit in a slot pool
-    [layers, 1 + slots, hidden] (row 0 = the all-zero start state); a round gathers by slot, runs the prediction
-    LSTM for one step and the joint, and `caiman_beam_topk` leaves [n, k] scores / tokens and [n] blank
-    log-probs in one buffer that is copied to pinned host memory."""
+    """One expansion round on the device, ~11 launches: index upload, input gather, per LSTM layer one library GEMM
+    + the cell kernel (new states scattered straight into the slot pool), joint_pred GEMM, relu(f + g), joint_fc
+    GEMM, `caiman_beam_topk`, one copy of the fixed-shape result to pinned host memory.
+
+    Prediction states of all live hypotheses sit in pools [layers, 1 + slots, hidden] (row 0 = the all-zero start
+    state; h in the compute dtype, c in f32).  Weights are re-laid once per compute dtype: [W_ih | W_hh] per layer,
+    b_ih + b_hh, everything cast to the autocast dtype when autocast is on."""
 
     def __init__(self, model, blank_idx: int, beam_width: int, temperature: float, eos_strategy=None):
-        self.model = getattr(model, "module", model)
+        self.model = m = getattr(model, "module", model)
         self.blank_idx, self.k, self.temperature = blank_idx, beam_width, temperature
         self.eos = (0, 0, 1.0, 0.0)
         if isinstance(eos_strategy, EOSIgnore):
@@ -167,59 +176,102 @@ class HipBeamStep:
             self.eos = (2, eos_strategy.eos_idx, 1.0, 0.0)
         elif isinstance(eos_strategy, EOSPredict):
             self.eos = (3, eos_strategy.eos_idx, float(eos_strategy.alpha), float(eos_strategy.beta))
+        rnn = m.prediction["dec_rnn"]
+        if rnn.batch_norm or getattr(rnn.lstm, "hard", False):
+            raise NotImplementedError("the fused beam round covers the plain (soft-activation, no batch-norm) "
+                                      "prediction LSTM of the shipped configs")
+        self.L, self.H = rnn.num_layers, m.pred_n_hid
+        self.w = {}          # compute dtype -> re-laid weights
         self.h_pool = self.c_pool = None
-        self.host = None
+        self.cap = 0
         self.stats = None
 
-    def _ensure(self, n_slots: int, n: int, dev, dtype):
-        m = self.model
-        if self.h_pool is None or self.h_pool.shape[1] < n_slots + 1:
-            cap = max(2 * n_slots, 64) + 1
-            L, H = m.prediction["dec_rnn"].num_layers, m.pred_n_hid
-            h = torch.zeros(L, cap, H, device=dev, dtype=dtype)
-            c = torch.zeros(L, cap, H, device=dev, dtype=dtype)
+    def _weights(self, cd):
+        w = self.w.get(cd)
+        if w is None:
+            m, lstm = self.model, self.model.prediction["dec_rnn"].lstm
+            with torch.no_grad():
+                w = dict(embed=m.prediction["embed"].weight.detach().to(cd).contiguous(),
+                         Wp=m.joint_pred.weight.detach().to(cd).contiguous(), bp=m.joint_pred.bias.detach().to(cd),
+                         Wf=m.joint_fc.weight.detach().to(cd).contiguous(), bf=m.joint_fc.bias.detach().to(cd))
+                for l in range(self.L):
+                    w[f"W{l}"] = torch.cat([getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}")], 1) \
+                        .detach().to(cd).contiguous()
+                    w[f"b{l}"] = (getattr(lstm, f"bias_ih_l{l}") + getattr(lstm, f"bias_hh_l{l}")).detach().to(cd)
+            self.w[cd] = w
+        return w
+
+    def refresh_weights(self):
+        """Call after the model's parameters changed."""
+        self.w = {}
+
+    def _ensure(self, n_slots: int, n: int, dev, cd):
+        L, H, k = self.L, self.H, self.k
+        if self.h_pool is None or self.h_pool.shape[1] < n_slots + 1 or self.h_pool.dtype != cd:
+            rows = max(2 * n_slots, 64) + 1
+            h = torch.zeros(L, rows, H, device=dev, dtype=cd)
+            c = torch.zeros(L, rows, H, device=dev, dtype=torch.float32)
             if self.h_pool is not None:
-                h[:, :self.h_pool.shape[1]] = self.h_pool
+                h[:, :self.h_pool.shape[1]] = self.h_pool.to(cd)
                 c[:, :self.c_pool.shape[1]] = self.c_pool
             self.h_pool, self.c_pool = h, c
-        if self.host is None or self.host.shape[0] < n:
-            cap = max(2 * n, 256)
-            self.host = torch.empty(cap, 2 * self.k + 1, dtype=torch.float32).pin_memory()
-            self.dev_out = torch.empty(cap, 2 * self.k + 1, dtype=torch.float32, device=dev)
+        if self.cap < n or self.X[0].dtype != cd:
+            cap = self.cap = max(2 * n, 256)
+            m = self.model
+            E, Hj, V = m.prediction["embed"].weight.shape[1], m.joint_pred.weight.shape[0], m.joint_fc.weight.shape[0]
+            self.idx_host = torch.empty(6, cap, dtype=torch.int32).pin_memory()    # y, in, out, row (int64 = 2 rows), pad
+            self.idx_dev = torch.empty(6, cap, dtype=torch.int32, device=dev)
+            self.X = [torch.empty(cap, (E if l == 0 else H) + H, device=dev, dtype=cd) for l in range(L)]
+            self.G_in = torch.empty(cap, H, device=dev, dtype=cd)
+            self.gates = torch.empty(cap, 4 * H, device=dev, dtype=cd)
+            self.g = torch.empty(cap, Hj, device=dev, dtype=cd)
+            self.A = torch.empty(cap, Hj, device=dev, dtype=cd)
+            self.logits = torch.empty(cap, V, device=dev, dtype=cd)
+            self.out_dev = torch.empty(cap * (2 * k + 1), dtype=torch.float32, device=dev)
+            self.out_host = torch.empty(cap * (2 * k + 1), dtype=torch.float32).pin_memory()
 
     @torch.no_grad()
-    def __call__(self, f: torch.Tensor, y_last: np.ndarray, state_in: np.ndarray, state_out: np.ndarray,
-                 n_slots: int):
-        """f [n, 1, Hj] encoder frames; y_last / state_in (-1 = start of sequence) / state_out [n] ->
-        (scores [n, k] f32, tokens [n, k] i32, blank [n] f32) numpy views of the pinned buffer."""
-        m, dev, n, k = self.model, f.device, f.shape[0], self.k
-        w = m.joint_enc.weight
-        self._ensure(n_slots, n, dev, w.dtype)
-        idx = torch.from_numpy(np.stack([y_last, state_in + 1, state_out + 1]).astype(np.int64)).to(dev, non_blocking=True)
-        y, s_in, s_out = idx[0], idx[1], idx[2]
-        emb = m.prediction["embed"](y.clamp(min=0)) * (y >= 0).unsqueeze(1).to(w.dtype)   # SOS: zero vector
-        h0, c0 = self.h_pool.index_select(1, s_in), self.c_pool.index_select(1, s_in)
-        g, (h1, c1), _ = m.prediction["dec_rnn"](emb.unsqueeze(0), (h0, c0))
-        self.h_pool.index_copy_(1, s_out, h1.to(self.h_pool.dtype))
-        self.c_pool.index_copy_(1, s_out, c1.to(self.c_pool.dtype))
-        g = m.joint_pred(g.transpose(0, 1))
-        logits = m.joint(f, g)[:, 0, 0, :]
-        if not logits.is_contiguous():
-            logits = logits.contiguous()
-        # tokens are written as int32 bit patterns into the float buffer; the three regions are separate
-        # contiguous blocks of one allocation so that a single copy brings them back
-        flat = self.dev_out.view(-1)
-        sc = flat[: n * k]
-        tk = flat[n * k: 2 * n * k].view(torch.int32)
-        bl = flat[2 * n * k: 2 * n * k + n]
-        L = _lib.lib()
-        _lib.check(L.caiman_beam_topk(_lib.ptr(logits), n, logits.shape[1], logits.stride(0), _lib.dtype_tag(logits.dtype),
-                                      self.temperature, self.blank_idx, self.eos[0], self.eos[1], self.eos[2],
-                                      self.eos[3], k, _lib.ptr(sc), _lib.ptr(tk), _lib.ptr(bl), _lib.stream()))
-        hflat = self.host.view(-1)
-        hflat[: 2 * n * k + n].copy_(flat[: 2 * n * k + n], non_blocking=True)
+    def __call__(self, frames2d: torch.Tensor, rows: np.ndarray, y_last: np.ndarray, state_in: np.ndarray,
+                 state_out: np.ndarray, n_slots: int):
+        """frames2d [R, Hj] encoder frames and, per request, the row to use; y_last / state_in (-1 = start of
+        sequence) / state_out [n] -> (scores [n, k] f32, tokens [n, k] i32, blank [n] f32): numpy views of the
+        pinned result buffer, valid until the next call."""
+        dev, n, k, L, H = frames2d.device, len(rows), self.k, self.L, self.H
+        cd = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else self.model.joint_fc.weight.dtype
+        if frames2d.dtype != cd:
+            frames2d = frames2d.to(cd)
+        assert frames2d.is_contiguous()
+        w = self._weights(cd)
+        self._ensure(n_slots, n, dev, cd)
+        ih = self.idx_host.numpy()
+        ih[0, :n], ih[1, :n], ih[2, :n] = y_last, state_in, state_out
+        ih[3:5].reshape(-1).view(np.int64)[:n] = rows
+        self.idx_dev.copy_(self.idx_host, non_blocking=True)
+        y, s_in, s_out = (_lib.ptr(self.idx_dev[i]) for i in range(3))
+        row = _lib.ptr(self.idx_dev[3])
+        lib, tag, st = _lib.lib(), _lib.dtype_tag(cd), _lib.stream()
+        E = w["embed"].shape[1]
+        _lib.check(lib.caiman_beam_gather_inputs(_lib.ptr(w["embed"]), E, _lib.ptr(self.h_pool[0]), H, y, s_in, n,
+                                                 _lib.ptr(self.X[0]), self.X[0].shape[1], tag, st))
+        for l in range(L):
+            torch.addmm(w[f"b{l}"], self.X[l][:n], w[f"W{l}"].t(), out=self.gates[:n])
+            nxt = self.X[l + 1] if l + 1 < L else self.G_in
+            _lib.check(lib.caiman_beam_lstm_cell(_lib.ptr(self.gates), H, _lib.ptr(self.c_pool[l]), _lib.ptr(self.h_pool[l]),
+                                                 _lib.ptr(self.h_pool[l + 1]) if l + 1 < L else None, s_in, s_out, n,
+                                                 _lib.ptr(nxt), nxt.shape[1], tag, st))
+        torch.addmm(w["bp"], self.G_in[:n], w["Wp"].t(), out=self.g[:n])
+        Hj = self.g.shape[1]
+        _lib.check(lib.caiman_beam_joint_act(_lib.ptr(frames2d), row, _lib.ptr(self.g), n, Hj, _lib.ptr(self.A), tag, st))
+        torch.addmm(w["bf"], self.A[:n], w["Wf"].t(), out=self.logits[:n])
+        flat = self.out_dev
+        sc, tk, bl = flat[: n * k], flat[n * k: 2 * n * k].view(torch.int32), flat[2 * n * k: 2 * n * k + n]
+        V = self.logits.shape[1]
+        _lib.check(lib.caiman_beam_topk(_lib.ptr(self.logits), n, V, V, tag, self.temperature, self.blank_idx,
+                                        self.eos[0], self.eos[1], self.eos[2], self.eos[3], k, _lib.ptr(sc),
+                                        _lib.ptr(tk), _lib.ptr(bl), st))
+        self.out_host[: 2 * n * k + n].copy_(flat[: 2 * n * k + n], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        hn = hflat.numpy()
+        hn = self.out_host.numpy()
         if self.stats is not None:   # [sum of top-1 probabilities, rows]: how peaked the workload is
             self.stats[0] += float(np.exp(hn[: n * k: k]).sum())
             self.stats[1] += n
@@ -237,7 +289,8 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
                  ngram_info=None, fuzzy_topk_logits: bool = False, return_partials: bool = False,
                  user_tokens: Optional[List[int]] = None, eos_is_terminal: bool = False,
                  eos_vad_threshold: float = INF, final_emission_thresh: float = INF,
-                 frame_width: Optional[float] = None, keyword_boost_path: Optional[str] = None, device_step=None):
+                 frame_width: Optional[float] = None, keyword_boost_path: Optional[str] = None, device_step=None,
+                 max_expansions_per_frame: int = 0):
         super().__init__(model=model, blank_idx=blank_idx, eos_strategy=eos_strategy,
                          max_inputs_per_batch=max_inputs_per_batch, max_symbol_per_sample=max_symbol_per_sample,
                          max_symbols_per_step=max_symbols_per_step, temperature=temperature)
@@ -260,14 +313,15 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
             beam_prune_score_thresh=beam_prune_score_thresh, beam_prune_topk_thresh=beam_prune_topk_thresh,
             eos_vad_threshold=eos_vad_threshold, final_emission_thresh=final_emission_thresh, frame_width=frame_width,
             eos_terminal_idx=(eos_strategy.eos_idx if eos_is_terminal and isinstance(eos_strategy, EOSPredict) else None),
-            return_partials=return_partials, keywords=kw, keyword_weights=kww)
+            return_partials=return_partials, keywords=kw, keyword_weights=kww,
+            max_expansions_per_frame=max_expansions_per_frame)
         self.step = device_step or HipBeamStep(self.model, blank_idx, beam_width, temperature, eos_strategy)
         self.profile: Optional[Dict[str, float]] = None   # set to a defaultdict(float) to collect host timings
 
-    def _rounds(self, search: NativeBeamSearch, frame_of, stop_below: int = 0):
+    def _rounds(self, search: NativeBeamSearch, frames2d: torch.Tensor, rows_of, stop_below: int = 0):
         """Expansion rounds until no stream has a request left -- or, with `stop_below`, until a round served no
-        more than that many streams (the stragglers carry on in the next call).  `frame_of(streams, frames)` ->
-        f [n, 1, Hj]."""
+        more than that many streams (the stragglers carry on in the next call).  `rows_of(streams, frames)` -> the
+        row of `frames2d` [R, Hj] holding each request's encoder frame."""
         n_rounds = 0
         prof = self.profile
         while True:
@@ -277,7 +331,7 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
                 return n_rounds
             n_rounds += 1
             t1 = time.perf_counter()
-            scores, tokens, blank = self.step(frame_of(stream, frame), y_last, s_in, s_out, search.state_slots())
+            scores, tokens, blank = self.step(frames2d, rows_of(stream, frame), y_last, s_in, s_out, search.state_slots())
             t2 = time.perf_counter()
             search.feed(scores, tokens, blank)
             if prof is not None:
@@ -298,14 +352,15 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
         B = len(lens)
         search = NativeBeamSearch(B, **self.search_args)
 
-        def frame_of(stream, frame):
-            rows = torch.from_numpy(stream.astype(np.int64)).to(encs.device)
-            cols = torch.from_numpy(frame.astype(np.int64)).to(encs.device)
-            return encs[rows, cols].unsqueeze(1)
+        T = encs.shape[1]
+        frames2d = encs.contiguous().view(B * T, -1)
+
+        def rows_of(stream, frame):
+            return stream.astype(np.int64) * T + frame
 
         for t in range(int(lens.max()) if B else 0):
             search.push_frame(np.nonzero(lens > t)[0])
-            self._rounds(search, frame_of)
+            self._rounds(search, frames2d, rows_of)
         for b in range(B):
             search.close_stream(b)
         self.model.train(was_training)
@@ -338,12 +393,8 @@ class StreamingBeamDecoder:
     def backlog(self) -> int:
         return self.search.backlog(-1)
 
-    def _frame_of(self, stream, frame):
-        if len(stream) == self.B and int(frame[0]) == int(frame[-1]) == self.n_frames - 1:
-            return self.frames[(self.n_frames - 1) % self.ring].unsqueeze(1)   # everyone on the newest frame, in order
-        dev = self.frames.device
-        idx = torch.from_numpy(np.stack([frame % self.ring, stream]).astype(np.int64)).to(dev, non_blocking=True)
-        return self.frames[idx[0], idx[1]].unsqueeze(1)
+    def _rows_of(self, stream, frame):
+        return (frame % self.ring).astype(np.int64) * self.B + stream
 
     @torch.no_grad()
     def step(self, feats: torch.Tensor) -> List[Dict[int, FrameResponses]]:
@@ -364,7 +415,8 @@ class StreamingBeamDecoder:
             self.frames[self.n_frames % self.ring] = f_all[:, j]
             self.n_frames += 1
             self.search.push_frame(self.all_streams)
-            self.rounds += self.dec._rounds(self.search, self._frame_of, stop_below=cutoff)
+            self.rounds += self.dec._rounds(self.search, self.frames.view(self.ring * self.B, -1), self._rows_of,
+                                            stop_below=cutoff)
         t0 = time.perf_counter()
         out = self.search.take_responses()
         if prof is not None:
@@ -372,7 +424,8 @@ class StreamingBeamDecoder:
         return out
 
     def close(self) -> List[Dict[int, FrameResponses]]:
-        self.rounds += self.dec._rounds(self.search, self._frame_of)   # let the stragglers finish
+        if self.frames is not None:   # let the stragglers finish
+            self.rounds += self.dec._rounds(self.search, self.frames.view(self.ring * self.B, -1), self._rows_of)
         for b in range(self.B):
             self.search.close_stream(b)
         return self.search.take_responses()

@@ -53,6 +53,25 @@ int caiman_beam_topk(const void* logits, int64_t n, int64_t vocab, int64_t row_s
                      float eos_alpha, float eos_beta, int32_t k, float* top_scores,
                      int32_t* top_tokens, float* blank_logp, caiman_stream_t stream);
 
+/* The memory-bound steps of one expansion round (prediction step + joint for n pending hypotheses; beam.py:564-612,
+ * rnnt/model.py:344-439).  With one timestep per call each LSTM layer is one library GEMM
+ * gates = [x | h_prev] · [W_ih | W_hh]^T + (b_ih + b_hh); these entry points do the gathers, the cell and the
+ * scatter around it.  State pools are [layers, 1 + slots, hidden]: row 0 is the zero start state, search slot s
+ * is row s + 1; h pools have the compute dtype, c pools are f32.
+ *   gather_inputs: X[i] = [ embed[y_last_i] (zeros when y_last_i < 0) | h_pool_l0[slot_in_i + 1] ]      X [n, ldx]
+ *   lstm_cell    : gates [n, 4·hidden] (order i,f,g,o: training/lib/csrc/lstm.cu:99-123) and c_pool_l[slot_in_i+1]
+ *                  -> c, h stored at row slot_out_i + 1 of this layer's pools; X_next[i] = [ h | h_pool_next[slot_in_i+1] ]
+ *                  (h_pool_next = the next layer's h pool, or NULL for the last layer: X_next[i] = h)
+ *   joint_act    : A[i] = relu(f_rows[row_i] + g[i])                          (rnnt/model.py:409-439, dropout off) */
+int caiman_beam_gather_inputs(const void* embed, int64_t embed_dim, const void* h_pool_l0, int64_t hidden,
+                              const int32_t* y_last, const int32_t* slot_in, int64_t n, void* X,
+                              int64_t ldx, int dtype, caiman_stream_t stream);
+int caiman_beam_lstm_cell(const void* gates, int64_t hidden, float* c_pool_l, void* h_pool_l,
+                          const void* h_pool_next, const int32_t* slot_in, const int32_t* slot_out,
+                          int64_t n, void* X_next, int64_t ldx, int dtype, caiman_stream_t stream);
+int caiman_beam_joint_act(const void* f_rows, const int64_t* row, const void* g, int64_t n,
+                          int64_t joint_dim, void* A, int dtype, caiman_stream_t stream);
+
 /* Search parameters: constructor arguments of RNNTBeamDecoder (beam.py:115-137). Thresholds < 0 mean
  * "off" (infinite), as in the reference (:153-154,190-200). */
 typedef struct {
@@ -67,6 +86,10 @@ typedef struct {
   double frame_width;             /* seconds per encoder frame */
   int32_t eos_terminal_idx;       /* token that ends a stream when predicted, or -1 */
   int32_t return_partials;
+  /* Serving safeguard, not in the reference (0 = off, the reference's behaviour): a frame on which a stream has
+   * expanded this many hypotheses is settled with the hypotheses closed so far, as if the open set had run dry
+   * (beam.py:410-413).  Bounds the work one stream can demand per frame. */
+  int32_t max_expansions_per_frame;
 } caiman_beam_config_t;
 
 typedef struct caiman_beam caiman_beam_t;
@@ -103,6 +126,8 @@ int caiman_beam_close_stream(caiman_beam_t* h, int32_t stream);
 int caiman_beam_stream_done(const caiman_beam_t* h, int32_t stream);
 /* Frames pushed but not yet finished on `stream`; stream = -1: the maximum over all streams. */
 int64_t caiman_beam_backlog(const caiman_beam_t* h, int32_t stream);
+/* Frames settled early by max_expansions_per_frame since the object was created. */
+int64_t caiman_beam_capped_frames(const caiman_beam_t* h);
 /* Number of state slots the device pool must hold (grows; check after caiman_beam_requests). */
 int64_t caiman_beam_state_slots(const caiman_beam_t* h);
 

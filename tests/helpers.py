@@ -104,10 +104,11 @@ class OracleBeamStep:
         self.dec, self.model, self.torch = decoder, model, torch
         self.states = {}
 
-    def __call__(self, f, y_last, state_in, state_out, n_slots):
+    def __call__(self, frames2d, rows, y_last, state_in, state_out, n_slots):
         import numpy as np
 
         torch, k = self.torch, self.dec.beam_width
+        f = frames2d[torch.from_numpy(np.asarray(rows, dtype=np.int64))].unsqueeze(1)
         sc, tk, bl = [], [], []
         for i in range(len(y_last)):
             if y_last[i] < 0:

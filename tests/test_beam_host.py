@@ -316,6 +316,35 @@ def test_native_search_threads_agree(monkeypatch):
     assert sum(len(r.final.alternatives[0].y_seq) for per in results[0] for r in per.values() if r.final) > n
 
 
+def test_native_search_expansion_cap():
+    """max_expansions_per_frame (a serving safeguard the reference lacks) bounds the rounds a frame can take and is
+    inert when it is not reached."""
+    from caiman_asr_amd.rnnt.beam_native import NativeBeamSearch
+
+    n, T = 24, 5
+    free = NativeBeamSearch(n, PIECES, blank_idx=28)
+    ref = _drive_synthetic(free, n, T)
+    assert free.capped_frames() == 0
+    loose = NativeBeamSearch(n, PIECES, blank_idx=28, max_expansions_per_frame=10_000)
+    assert _drive_synthetic(loose, n, T) == ref and loose.capped_frames() == 0
+    tight = NativeBeamSearch(n, PIECES, blank_idx=28, max_expansions_per_frame=2)
+    rounds = 0
+    for t in range(T):
+        tight.push_frame(np.arange(n))
+        while True:
+            stream, frame, y, s_in, s_out = tight.requests()
+            if len(stream) == 0:
+                break
+            rounds += 1
+            sc = np.log(np.tile(np.array([[0.3, 0.28, 0.22, 0.2]], np.float32), (len(stream), 1)))
+            tk = np.tile(np.array([[3, 4, 5, 28]], np.int32), (len(stream), 1))
+            tight.feed(sc, tk, np.log(np.full(len(stream), 0.2, np.float32)))
+    assert rounds == 2 * T and tight.capped_frames() == n * T and tight.backlog() == 0
+    for b in range(n):
+        tight.close_stream(b)
+    assert all(len(r) > 0 for r in tight.take_responses())
+
+
 def test_beam_limits_and_errors():
     g, m = _oracle_model()
     V = int(g["n_classes"])
