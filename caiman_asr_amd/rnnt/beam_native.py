@@ -318,10 +318,12 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
         self.step = device_step or HipBeamStep(self.model, blank_idx, beam_width, temperature, eos_strategy)
         self.profile: Optional[Dict[str, float]] = None   # set to a defaultdict(float) to collect host timings
 
-    def _rounds(self, search: NativeBeamSearch, frames2d: torch.Tensor, rows_of, stop_below: int = 0):
+    def _rounds(self, search: NativeBeamSearch, frames2d: torch.Tensor, rows_of, stop_below: int = 0,
+                deadline: Optional[float] = None):
         """Expansion rounds until no stream has a request left -- or, with `stop_below`, until a round served no
-        more than that many streams (the stragglers carry on in the next call).  `rows_of(streams, frames)` -> the
-        row of `frames2d` [R, Hj] holding each request's encoder frame."""
+        more than that many streams (the stragglers carry on in the next call; with a `deadline`, a perf_counter
+        time, they are still served until then).  `rows_of(streams, frames)` -> the row of `frames2d` [R, Hj] holding
+        each request's encoder frame."""
         n_rounds = 0
         prof = self.profile
         while True:
@@ -341,7 +343,7 @@ class RNNTBeamDecoderNative(RNNTCommonDecoder):
                 prof["feed"] += t3 - t2
                 prof["rounds"] += 1
                 prof["expansions"] += len(stream)
-            if len(stream) <= stop_below:
+            if len(stream) <= stop_below and (deadline is None or time.perf_counter() >= deadline):
                 return n_rounds
 
     @torch.no_grad()
@@ -374,18 +376,19 @@ class StreamingBeamDecoder:
 
     A frame on which a stream's beam is slow to settle can need a hundred expansions while the typical one needs
     a handful; waiting for it would make every stream late.  With `straggler_cutoff` > 0 a tick ends once a round
-    served no more than that many streams: those streams keep their open frame, queue the frames that arrive
-    meanwhile (`ring` encoder frames are kept) and catch up inside later ticks.  `backlog()` reports the lag."""
+    served no more than that many streams (and `tick_budget_s`, if given, has been used up): those streams keep
+    their open frame, queue the frames that arrive meanwhile (`ring` encoder frames are kept) and catch up inside
+    later ticks.  `backlog()` reports the lag."""
 
     def __init__(self, model, blank_idx: int, n_streams: int, sentpiece_model: Union[str, Sequence[str]],
-                 straggler_cutoff: int = 0, ring: int = 32, **kwargs):
+                 straggler_cutoff: int = 0, ring: int = 32, tick_budget_s: Optional[float] = None, **kwargs):
         self.dec = RNNTBeamDecoderNative(model, blank_idx, kwargs.pop("eos_strategy", None), sentpiece_model, **kwargs)
         self.model = self.dec.model
         self.B = n_streams
         self.encoder = StreamingEncoder(self.model, n_streams)
         self.search = NativeBeamSearch(n_streams, **self.dec.search_args)
         self.all_streams = np.arange(n_streams, dtype=np.int32)
-        self.straggler_cutoff, self.ring = straggler_cutoff, ring
+        self.straggler_cutoff, self.ring, self.tick_budget_s = straggler_cutoff, ring, tick_budget_s
         self.frames = None        # [ring, N, Hj] the most recent encoder frames
         self.n_frames = 0
         self.rounds = 0
@@ -401,6 +404,7 @@ class StreamingBeamDecoder:
         self.model.eval()
         prof = self.dec.profile
         t0 = time.perf_counter()
+        deadline = None if self.tick_budget_s is None else t0 + self.tick_budget_s
         f_all = self.encoder.advance(feats)
         if prof is not None:
             torch.cuda.synchronize()
@@ -416,7 +420,7 @@ class StreamingBeamDecoder:
             self.n_frames += 1
             self.search.push_frame(self.all_streams)
             self.rounds += self.dec._rounds(self.search, self.frames.view(self.ring * self.B, -1), self._rows_of,
-                                            stop_below=cutoff)
+                                            stop_below=cutoff, deadline=deadline)
         t0 = time.perf_counter()
         out = self.search.take_responses()
         if prof is not None:
