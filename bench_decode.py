@@ -173,6 +173,45 @@ def main():
             fit_blank_bias(scale)
         dec = new_decoder(args.streams, cutoff=int(args.straggler_frac * args.streams))
     else:
+        # closed loop on short greedy decodes: bisect the blank bias until `emit_rate` tokens per frame are emitted
+        def greedy_rate(n=256, ticks=40, settle=20):
+            d = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=n, max_symbols_per_step=args.max_symbols)
+            gen = torch.Generator(device=dev).manual_seed(1)
+            tok = frames = 0
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                for i in range(ticks):
+                    for _, n_emit in d.step(torch.randn(2, n, 240, device=dev, generator=gen)):
+                        if i >= settle:
+                            tok += int(n_emit.sum().item())
+                            frames += n
+            return tok / max(frames, 1)
+
+        def rate(b):
+            with torch.no_grad():
+                set_scale(scale, b)
+            return greedy_rate()
+
+        b0, step = blank_shift(scale), max(1.0, 0.5 * scale * float(raw[:, :-1].std()))
+        lo = hi = b0
+        for _ in range(16):
+            if rate(hi) <= args.emit_rate:
+                break
+            lo, hi = hi, hi + step
+            step *= 2
+        for _ in range(16):
+            if lo < hi and rate(lo) > args.emit_rate:
+                break
+            lo -= step
+            step *= 2
+        for _ in range(8):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if rate(mid) > args.emit_rate else (lo, mid)
+        # the rate can be steep in the bias: settle on the bracket end whose rate is closer to the target
+        import math
+
+        ends = [(abs(math.log(max(rate(b), 1e-4) / args.emit_rate)), b) for b in (lo, hi)]
+        best = min(ends)[1]
+        print(f"[bench_decode] blank bias {b0:.2f} -> {best:.2f}: greedy tokens/frame {rate(best):.3f}", file=sys.stderr)
         dec = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=args.streams, max_symbols_per_step=args.max_symbols)
     feats = [torch.randn(2, args.streams, 240, device=dev) for _ in range(64)]
     import gc
