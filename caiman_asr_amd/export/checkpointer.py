@@ -4,8 +4,7 @@ Mirror of training/caiman_asr_train/export/checkpointer.py:20-231: `<name>_step{
 `_best_` / `_last_` files holding `{epoch, step, best_wer, state_dict, ema_state_dict, optimizer, tokenizer_kw,
 logmel_norm_weight}` (keys pinned by training/tests/export/test_checkpointer.py:76-132).  `state_dict` uses the
 reference's parameter names (RNNT.state_dict drops the aliased joint_fc.* keys), so a checkpoint written by
-either implementation loads in the other.  The FPGA hand-off file (`.hw.pt`, hardware_ckpt.py) is a "next"
-row of SURVEY §8f and is not written here.
+either implementation loads in the other.  The inference hand-off file is written by `export/hardware_ckpt.py`.
 """
 import glob
 import os

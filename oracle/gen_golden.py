@@ -225,6 +225,29 @@ def main():
         print("beam", tag, [len(u["tokens"]) for u in per_utt], [u["last_key"] for u in per_utt])
     json.dump(dict(pieces=pieces, unk_bias=-30.0, results=beam_out), open(os.path.join(OUT, "beam_mfma.json"), "w"))
 
+    # ---- 2c. inference-only config filter + the reference's own hardware-checkpoint fixture ----------------------
+    from caiman_asr_train.export.config_schema import RNNTInferenceConfigSchema
+    import yaml   # the reference's rnnt/config.py pulls in DALI; its load() is these two yaml calls (config.py:44-48)
+
+    class _NoAlias(yaml.SafeDumper):
+        def ignore_aliases(self, data):
+            return True
+
+    inf = {}
+    for name in ("base-8703sp", "large-17407sp", "testing-1023sp", "testing-1023sp_run", "librispeech"):
+        full = yaml.safe_load(yaml.dump(yaml.safe_load(open(f"{REF}/configs/{name}.yaml")), Dumper=_NoAlias))
+        try:
+            inf[name] = dict(full=full, inference=RNNTInferenceConfigSchema(**full).model_dump())
+        except Exception as e:  # a config the reference itself rejects is a fixture too
+            inf[name] = dict(full=full, error=type(e).__name__)
+        print("inference config", name, "error" if "error" in inf[name] else "ok")
+    hw = torch.load(f"{REF}/tests/test_data/hardware_ckpt.pt", map_location="cpu", weights_only=False)
+    hw_meta = dict(keys=sorted(hw), rnnt_config=hw["rnnt_config"], melalpha=hw["melalpha"], epoch=hw["epoch"], step=hw["step"],
+                   best_wer=hw["best_wer"], ngram_keys=sorted(hw["ngram"]), ngram_binary_is_bytes=isinstance(hw["ngram"]["binary"], bytes),
+                   sentpiece_is_bytes=isinstance(hw["sentpiece_model"], bytes), mel_shape=list(hw["melmeans"].shape),
+                   mel_dtype=str(hw["melmeans"].dtype), state_dict={k: list(v.shape) for k, v in hw["state_dict"].items()})
+    json.dump(dict(configs=inf, hardware_ckpt=hw_meta), open(os.path.join(OUT, "export.json"), "w"))
+
     # ---- 3. small pure functions ---------------------------------------------------------
     torch.manual_seed(7)
     x = torch.randn(9, 2, 5)
