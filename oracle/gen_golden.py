@@ -14,6 +14,7 @@ so they are replaced by in-memory no-op stand-ins (nothing is written anywhere):
 
 Usage:  python oracle/gen_golden.py
 """
+import itertools
 import json
 import os
 import sys
@@ -37,6 +38,15 @@ def _install_stubs():
             return a[0]
         return lambda f: f
 
+    def chunked(iterable, n):   # more_itertools.chunked (absent here): consecutive lists of n items, the last one shorter
+        it = iter(iterable)
+        while True:
+            chunk = list(itertools.islice(it, n))
+            if not chunk:
+                return
+            yield chunk
+
+    stub("more_itertools", chunked=chunked)
     stub("beartype", beartype=ident)
     btt = stub("beartype.typing")
     btt.__dict__.update({k: getattr(typing, k) for k in dir(typing) if not k.startswith("_")})
@@ -247,6 +257,56 @@ def main():
                    sentpiece_is_bytes=isinstance(hw["sentpiece_model"], bytes), mel_shape=list(hw["melmeans"].shape),
                    mel_dtype=str(hw["melmeans"].dtype), state_dict={k: list(v.shape) for k, v in hw["state_dict"].items()})
     json.dump(dict(configs=inf, hardware_ckpt=hw_meta), open(os.path.join(OUT, "export.json"), "w"))
+
+    # ---- 2d. samplers: utterance order per rank for seeded synthetic manifests -----------------------------------
+    from caiman_asr_train.data.dali import manifest_ratios as mr
+    from caiman_asr_train.data.dali import sampler as ref_sampler
+
+    srng = np.random.default_rng(11)
+    manifests, label = [], 0
+    for m_i, n_utt in enumerate((96, 160, 64)):
+        man = {}
+        for j in range(n_utt):
+            man[f"m{m_i}/utt{j:04d}.flac"] = {"label": label, "duration": float(np.round(srng.uniform(1.0, 16.7), 2))}
+            label += 1
+        manifests.append(man)
+    names = ["m0.json", "m1.json", "m2.json"]
+    sampler_cases = {
+        "simple_w1": ("SimpleSampler", dict(total_batches=None, batch_size=8, global_batch_size=None, world_size=1), None, None),
+        "simple_w4": ("SimpleSampler", dict(total_batches=None, batch_size=8, global_batch_size=None, world_size=4), None, None),
+        "sorted_w1": ("SortedSampler", dict(total_batches=None, batch_size=8, global_batch_size=None, world_size=1), None, None),
+        "sorted_w4": ("SortedSampler", dict(total_batches=None, batch_size=8, global_batch_size=None, world_size=4), None, None),
+        "random_w2": ("RandomSampler", dict(total_batches=200, batch_size=4, global_batch_size=16, world_size=2, resume_step=0), 5, None),
+        "bucket_w1": ("BucketingSampler", dict(total_batches=90, batch_size=8, global_batch_size=32, world_size=1, resume_step=0, num_buckets=6), 7, None),
+        "bucket_w4": ("BucketingSampler", dict(total_batches=200, batch_size=4, global_batch_size=32, world_size=4, resume_step=0, num_buckets=6), 7, None),
+        "bucket_w4_resume": ("BucketingSampler", dict(total_batches=200, batch_size=4, global_batch_size=32, world_size=4, resume_step=3, num_buckets=6), 7, None),
+        "bucket_one_epoch_w4": ("BucketingSampler", dict(total_batches=40, batch_size=4, global_batch_size=32, world_size=4, resume_step=0, num_buckets=6), 7, None),
+        "bucket_nopess": ("BucketingSampler", dict(total_batches=100, batch_size=8, global_batch_size=16, world_size=2, resume_step=0, num_buckets=3,
+                                                         pessimistic_first_batch=False), 9, None),
+        "bucket_pess_rand1": ("BucketingSampler", dict(total_batches=100, batch_size=8, global_batch_size=16, world_size=2, resume_step=0, num_buckets=3,
+                                                       randomize_n_epochs=1), 9, None),
+        "bucket_relative": ("BucketingSampler", dict(total_batches=150, batch_size=4, global_batch_size=16, world_size=2, resume_step=0, num_buckets=4), 3,
+                            ("relative", [1.0, 0.5, 2.0])),
+        "bucket_absolute": ("BucketingSampler", dict(total_batches=150, batch_size=4, global_batch_size=16, world_size=2, resume_step=0, num_buckets=4), 3,
+                            ("absolute", [1.0, 1.0, 1.0])),
+        "bucket_canary": ("BucketingSampler", dict(total_batches=150, batch_size=4, global_batch_size=16, world_size=2, resume_step=0, num_buckets=4), 3,
+                          ("canary", 0.5)),
+    }
+    sampler_out = {}
+    for tag, (klass, kw, seed, ratios) in sampler_cases.items():
+        kw2 = dict(kw)
+        if seed is not None:
+            kw2["rng"] = np.random.default_rng(seed)
+        smp = getattr(ref_sampler, klass)(**kw2)
+        ratio_obj = None
+        if ratios is not None:
+            ratio_obj = {"relative": mr.RelativeManifestRatios, "absolute": mr.AbsoluteManifestRatios,
+                         "canary": mr.CanaryManifestRatios}[ratios[0]](ratios[1])
+        files, epoch_size = smp.process_output_files([dict(m) for m in manifests], names, ratio_obj)
+        sampler_out[tag] = dict(klass=klass, kwargs=kw, seed=seed, ratios=ratios, epoch_size=epoch_size,
+                                labels=[u.label for u in files])
+        print("sampler", tag, len(files), epoch_size)
+    json.dump(dict(manifests=manifests, names=names, cases=sampler_out), open(os.path.join(OUT, "sampler.json"), "w"))
 
     # ---- 3. small pure functions ---------------------------------------------------------
     torch.manual_seed(7)
