@@ -47,6 +47,8 @@ def _install_stubs():
             yield chunk
 
     stub("more_itertools", chunked=chunked)
+    stub("orjson", loads=json.loads, dumps=lambda o, option=None: json.dumps(o).encode(), OPT_INDENT_2=0)  # absent; std json reads the same
+    stub("sox")   # only used by the reference to build a manifest from a directory of audio files
     stub("beartype", beartype=ident)
     btt = stub("beartype.typing")
     btt.__dict__.update({k: getattr(typing, k) for k in dir(typing) if not k.startswith("_")})
@@ -307,6 +309,30 @@ def main():
                                 labels=[u.label for u in files])
         print("sampler", tag, len(files), epoch_size)
     json.dump(dict(manifests=manifests, names=names, cases=sampler_out), open(os.path.join(OUT, "sampler.json"), "w"))
+
+    # ---- 2e. manifest parsing / filtering -------------------------------------------------------------------------
+    from caiman_asr_train.data.dali import utils as ref_dutils
+
+    mrng = np.random.default_rng(4)
+    entries = []
+    for i in range(14):
+        n_words = int(mrng.integers(1, 12))
+        entries.append({"transcript": " ".join("w%d" % int(mrng.integers(0, 50)) for _ in range(n_words)),
+                        "files": [{"fname": f"slow/utt{i}.flac"}, {"fname": f"clips/utt{i}.flac"}],
+                        "original_duration": float(np.round(mrng.uniform(0.02, 20.0), 2))})
+    man_path = os.path.join(OUT, "_manifest_tmp.json")
+    json.dump(entries, open(man_path, "w"))
+    pred = ref_dutils.set_predicate(16.7, 40)
+    files_all, tr_all = ref_dutils._parse_json(man_path)
+    files_f, tr_f = ref_dutils._parse_json(man_path, 7, pred)
+    sub_files, sub_tr = ref_dutils._filter_files(dict(files_all), dict(tr_all), 5, 3)
+    os.remove(man_path)
+    json.dump(dict(entries=entries, parsed=dict(files=files_all, transcripts={str(k): v for k, v in tr_all.items()}),
+                   filtered=dict(start_label=7, max_duration=16.7, max_transcript_len=40, files=files_f,
+                                 transcripts={str(k): v for k, v in tr_f.items()}),
+                   subset=dict(n=5, seed=3, files=sub_files, order=list(sub_files), transcripts={str(k): v for k, v in sub_tr.items()})),
+              open(os.path.join(OUT, "manifest.json"), "w"))
+    print("manifest", len(files_all), len(files_f), len(sub_files))
 
     # ---- 3. small pure functions ---------------------------------------------------------
     torch.manual_seed(7)
