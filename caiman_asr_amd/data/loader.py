@@ -69,7 +69,8 @@ class AudioBatchLoader:
                 lens = self._decode(batch, pool[slot])
                 n_max = int(lens.max())
                 with torch.cuda.stream(stream), torch.no_grad():
-                    audio = pool[slot][: len(batch), :n_max].to(self.device, non_blocking=True)
+                    # whole rows: a contiguous pinned block is one asynchronous DMA, a strided slice is not
+                    audio = pool[slot][: len(batch)].to(self.device, non_blocking=True)[:, :n_max].contiguous()
                     free_at[slot] = torch.cuda.Event()
                     free_at[slot].record(stream)
                     a_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
