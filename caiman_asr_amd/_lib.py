@@ -131,6 +131,7 @@ _SIGS = {
     "caiman_audio_info": ([P, I64, P, P, P], ctypes.c_int),
     "caiman_audio_decode": ([P, I64, P, I64, P, P], ctypes.c_int),
     "caiman_audio_decode_files": ([ctypes.POINTER(ctypes.c_char_p), I32, P, I64, P, P, I32], ctypes.c_int),
+    "caiman_levenshtein": ([P, I64, P, I64], ctypes.c_int64),
     # include/caiman_beam.h
     "caiman_beam_topk": ([P, I64, I64, I64, I32, F32, I32, I32, I32, F32, F32, I32, P, P, P, P], ctypes.c_int),
     "caiman_beam_gather_inputs": ([P, I64, P, I64, P, P, I64, P, I64, I32, P], ctypes.c_int),

@@ -33,6 +33,11 @@ int caiman_audio_decode(const uint8_t* data, int64_t size, float* out, int64_t c
 int caiman_audio_decode_files(const char* const* paths, int32_t n, float* out, int64_t max_frames,
                               int32_t* lengths, int32_t* sample_rates, int32_t n_threads);
 
+/* Levenshtein distance between two sequences of ids (insert / delete / substitute, unit costs): the kernel of the
+ * reference's WER, which it takes from the Rust extension `levenshtein_rs`
+ * (training/caiman_asr_train/evaluate/metrics.py:20,123).  Returns the distance, or -1 on error. */
+int64_t caiman_levenshtein(const int32_t* a, int64_t n, const int32_t* b, int64_t m);
+
 #ifdef __cplusplus
 }
 #endif

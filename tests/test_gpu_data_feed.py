@@ -109,3 +109,44 @@ def test_training_step_from_files(tmp_path):
         loss.backward()
         assert torch.isfinite(loss)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_evaluate_files_to_wer(tmp_path):
+    """files -> loader -> greedy / native beam decode -> detokenise -> WER; the number equals scoring the decoders'
+    own outputs by hand, and a model that is told the answer scores 0."""
+    from caiman_asr_amd.data.frontend import LogMelFrontend
+    from caiman_asr_amd.data.loader import AudioBatchLoader
+    from caiman_asr_amd.evaluate.core import evaluate
+    from caiman_asr_amd.evaluate.metrics import word_error_rate
+    from caiman_asr_amd.rnnt.beam_native import RNNTBeamDecoderNative
+    from caiman_asr_amd.rnnt.decoder import RNNTBatchedGreedyDecoder, flatten_responses
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    utts, audio, toks = _corpus(tmp_path, n=7)
+    fe = LogMelFrontend(dither=0.0, device=DEV)
+    torch.manual_seed(1)
+    m = RNNT(n_classes=29, in_feats=240, enc_n_hid=64, enc_pre_rnn_layers=1, enc_post_rnn_layers=1, enc_stack_time_factor=2,
+             enc_dropout=0.0, enc_batch_norm=False, pred_n_hid=32, pred_rnn_layers=1, pred_dropout=0.0, pred_batch_norm=False,
+             joint_n_hid=48, joint_dropout=0.0, forget_gate_bias=1.0, custom_lstm=True).to(DEV).eval()
+    with torch.no_grad():
+        m.joint_fc.weight.mul_(8.0)
+        m.joint_fc.bias[0] = -50.0
+    pieces = ["<unk>"] + [("▁" if i % 2 else "") + chr(96 + i) for i in range(1, 27)] + ["▁zz"]
+    detok = lambda ids: "".join(pieces[i] for i in ids).replace("▁", " ").strip()
+    greedy = RNNTBatchedGreedyDecoder(m, 28, None, int(1e7), None, max_symbols_per_step=3)
+    beam = RNNTBeamDecoderNative(m, 28, None, pieces, max_symbols_per_step=3)
+    for dec in (greedy, beam):
+        loader = AudioBatchLoader(utts, toks, str(tmp_path), 4, fe, device=DEV)
+        res = evaluate(loader, dec, detok, autocast_dtype=None, standardize=False)
+        assert len(res["hypotheses"]) == 8 and res["words"] == sum(len(r.split()) for r in res["references"]) > 0
+        hyps = []
+        for feats, f_lens, txt, t_lens in AudioBatchLoader(utts, toks, str(tmp_path), 4, fe, device=DEV):
+            hyps += [detok(t) for t in flatten_responses(dec.decode(feats, f_lens))[0]]
+        assert hyps == res["hypotheses"]
+        assert (res["wer"], res["errors"], res["words"]) == word_error_rate(hyps, res["references"], standardize=False)
+    perfect = evaluate([(None, None, torch.tensor([[3, 4]]), torch.tensor([2]))],
+                       type("Echo", (), {"decode": lambda self, f, l: [{0: __import__("caiman_asr_amd.rnnt.response", fromlist=["x"]).FrameResponses(
+                           None, __import__("caiman_asr_amd.rnnt.response", fromlist=["x"]).DecodingResponse(0, 1, False, [
+                               __import__("caiman_asr_amd.rnnt.response", fromlist=["x"]).HypothesisResponse([3, 4], [0, 0], ["c", "d"], [1.0, 1.0])]))}]})(),
+                       detok, autocast_dtype=None)
+    assert perfect["wer"] == 0.0
