@@ -144,9 +144,12 @@ def test_evaluate_files_to_wer(tmp_path):
             hyps += [detok(t) for t in flatten_responses(dec.decode(feats, f_lens))[0]]
         assert hyps == res["hypotheses"]
         assert (res["wer"], res["errors"], res["words"]) == word_error_rate(hyps, res["references"], standardize=False)
-    perfect = evaluate([(None, None, torch.tensor([[3, 4]]), torch.tensor([2]))],
-                       type("Echo", (), {"decode": lambda self, f, l: [{0: __import__("caiman_asr_amd.rnnt.response", fromlist=["x"]).FrameResponses(
-                           None, __import__("caiman_asr_amd.rnnt.response", fromlist=["x"]).DecodingResponse(0, 1, False, [
-                               __import__("caiman_asr_amd.rnnt.response", fromlist=["x"]).HypothesisResponse([3, 4], [0, 0], ["c", "d"], [1.0, 1.0])]))}]})(),
-                       detok, autocast_dtype=None)
+    from caiman_asr_amd.rnnt.response import DecodingResponse, FrameResponses, HypothesisResponse
+
+    class Echo:   # a "decoder" that is told the answer
+        def decode(self, feats, feat_lens):
+            final = DecodingResponse(0, 1, False, [HypothesisResponse([3, 4], [0, 0], ["c", "d"], [1.0, 1.0])])
+            return [{0: FrameResponses(None, final)}]
+
+    perfect = evaluate([(None, None, torch.tensor([[3, 4]]), torch.tensor([2]))], Echo(), detok, autocast_dtype=None)
     assert perfect["wer"] == 0.0
