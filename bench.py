@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient GEMMs on the main stream")
+    ap.add_argument("--main-priority", type=int, default=0,
+                    help="run the step on a stream of this priority (-1 = above the side streams; 0 = the default stream; measured: no effect)")
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
     args = ap.parse_args()
 
@@ -194,6 +196,18 @@ def main():
             reducer.finish()
         optimizer.step(zero_grad=True)
         return loss.detach(), float(lens_h.sum()) * FRAME_SECONDS, meta["packed_batch"]
+
+    if args.main_priority != 0:
+        # The critical path (LSTM step kernels, joint backward) is a chain of short kernels; the side streams carry
+        # long GEMMs that would otherwise occupy every CU first.  A higher-priority main stream gets its workgroups
+        # dispatched ahead of theirs.
+        main_stream = torch.cuda.Stream(device=dev, priority=args.main_priority)
+        main_stream.wait_stream(torch.cuda.current_stream())
+        plain_step = step
+
+        def step(i, global_step):  # noqa: F811
+            with torch.cuda.stream(main_stream):
+                return plain_step(i, global_step)
 
     def log(msg):
         if rank == 0:

@@ -148,6 +148,9 @@ class StackFunction(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, d_top, d_allh, _d_allc):
         L, T, B, H, hard, drop, seed, need_dx = ctx.meta
+        from caiman_asr_amd.train_utils import overlap
+
+        overlap.flush_deferred()   # nothing upstream claimed them (unpacked joint): let held-back GEMMs go now
         saved = ctx.saved_tensors
         x, G, Y, Cs = saved[:4]
         Wp, Rp = saved[4:4 + L], saved[4 + L:4 + 2 * L]

@@ -6,11 +6,15 @@ latency-bound step kernels that leaves the matrix cores idle, so the big `dW = d
 second HIP stream and accumulate straight into the parameter's gradient (a view of the flat arena).
 `wait_all()` must be called before the gradients are consumed (reducer.finish() / optimizer.step()).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 _side = {}
 _pending = False
+_deferred = []   # closures that launch side-stream work; run by flush_deferred()
+DEFER = os.environ.get("CAIMAN_DEFER", "1") != "0"   # hold the joint projection's weight-gradient GEMM back until the joint's own backward is queued
 _grad_ready_callbacks = []  # called as cb(param) right after a side-stream accumulation has been queued
 
 
@@ -33,9 +37,22 @@ def side_stream(device) -> torch.cuda.Stream:
     return _side[key]
 
 
+def flush_deferred():
+    """Launch side-stream work that was held back.  A long GEMM launched on the side stream the moment its inputs
+    exist fills every CU and starves the short kernel that comes next on the critical path (the joint's backward
+    reduction went from 0.4 ms to 3.7 ms); so the producer only files the launch, and the next stage of the backward
+    pass calls this right after queueing its own first kernel."""
+    global _deferred
+    if _deferred:
+        todo, _deferred = _deferred, []
+        for launch in todo:
+            launch()
+
+
 def wait_all():
     """Make the current stream wait for every side-stream gradient GEMM issued so far."""
     global _pending
+    flush_deferred()
     if _pending:
         for s in _side.values():
             torch.cuda.current_stream().wait_stream(s)
@@ -68,16 +85,26 @@ class _LinearOverlapped(torch.autograd.Function):
         dx = torch.matmul(dy, weight.to(dy.dtype)) if ctx.needs_input_grad[0] else None
         main = torch.cuda.current_stream()
         side = side_stream(dy.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            dy2 = dy.reshape(-1, dy.shape[-1])
-            x2 = x.reshape(-1, x.shape[-1]).to(dy.dtype)
-            _accumulate(weight, torch.matmul(dy2.t(), x2))
-            if bias is not None:
-                _accumulate(bias, dy2.sum(0))
-        for t in (dy, x):
-            t.record_stream(side)
-        _pending = True
+        ready = torch.cuda.Event()
+        ready.record(main)          # dy and x are complete here, whatever the main stream does afterwards
+
+        def launch():
+            global _pending
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                dy2 = dy.reshape(-1, dy.shape[-1])
+                x2 = x.reshape(-1, x.shape[-1]).to(dy.dtype)
+                _accumulate(weight, torch.matmul(dy2.t(), x2))
+                if bias is not None:
+                    _accumulate(bias, dy2.sum(0))
+            for t in (dy, x):
+                t.record_stream(side)
+            _pending = True
+
+        if DEFER:
+            _deferred.append(launch)
+        else:
+            launch()
         return dx, None, None
 
 
