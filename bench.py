@@ -236,6 +236,7 @@ def main():
     barrier()
     if not args.no_kernel_timing:
         _lib.timing.enabled = True
+        _lib.timing.sample_every = {"lstm_fwd": 8, "lstm_bwd": 8}   # see _lib._Timing: every bracket would cost 13 %
         _lib.timing.reset()
     audio_s, cells = 0.0, 0
     t0 = time.perf_counter()
@@ -299,7 +300,20 @@ def main():
                                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                    "avg_launch_us": ms * 1e3 / launches, "launches": launches,
-                                   "algorithmic_bytes_per_launch": nbytes / launches}
+                                   "algorithmic_bytes_per_launch": nbytes / launches,
+                                   "note": ("avg_launch_us is event-to-event over sampled runs of back-to-back dependent "
+                                            "launches, i.e. kernel time + the ~1.6 us kernel boundary + the events' own "
+                                            "cost; the kernel alone is `rocprof_kernel_avg_us` (profiles/)")}
+                try:   # the committed rocprofv3 --kernel-trace --stats summary of this command
+                    import csv
+
+                    with open(os.path.join(ROOT, "profiles", "r01_bench_v7_kernel_stats.csv")) as f:
+                        for row in csv.DictReader(f):
+                            if "lstm_bwd_step_mfma" in row["Name"] and "Li8E" in row["Name"]:
+                                out["roofline"]["rocprof_kernel_avg_us"] = float(row["AverageNs"]) / 1e3
+                                break
+                except Exception:
+                    pass
             if "loss_bwd" in summ:
                 n_launch, ms = summ["loss_bwd"][0], summ["loss_bwd"][1]
                 alg = cells * N_CLASSES * 2 * 2  # V*s read + V*s write per lattice cell

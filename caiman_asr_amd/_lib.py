@@ -223,12 +223,25 @@ def check_input(t, name):
 
 # ---- optional per-op HIP event timing (used by bench.py for the roofline line) -----------------
 class _Timing:
+    """`sample_every[name] = k`: only about one in k brackets of that name is timed (pseudo-randomly chosen) and the
+    summary scales the totals back up.  An event pair between two dependent kernels costs more than the few
+    microseconds it takes to record: the fence it carries writes back / invalidates the L2 that the next LSTM step
+    wants warm.  Timing every one of the ~200 LSTM brackets of a step slowed the step by 13 %."""
+
     def __init__(self):
         self.enabled = False
         self.records = {}
+        self.sample_every = {}
+        self.seen = {}
 
     def reset(self):
         self.records = {}
+        self.seen = {}
+
+    def take(self, name) -> bool:
+        k = self.sample_every.get(name, 1)
+        n = self.seen[name] = self.seen.get(name, 0) + 1
+        return k <= 1 or ((n * 2654435761) >> 7) % k == 0
 
 
 timing = _Timing()
@@ -244,15 +257,16 @@ class timed:
         self.name = name
         self.units = units      # kernel launches of the dominant kernel inside the bracket
         self.nbytes = nbytes    # algorithmic bytes moved inside the bracket
+        self.start = None
 
     def __enter__(self):
-        if timing.enabled:
+        if timing.enabled and timing.take(self.name):
             self.start = torch.cuda.Event(enable_timing=True)
             self.start.record()
         return self
 
     def __exit__(self, *exc):
-        if timing.enabled:
+        if self.start is not None:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
             timing.records.setdefault(self.name, []).append((self.start, end, self.units, self.nbytes))
@@ -260,7 +274,12 @@ class timed:
 
 
 def timing_summary():
-    """{name: (calls, total_ms, kernel launches, algorithmic bytes)}; synchronises."""
+    """{name: (brackets, total_ms, kernel launches, algorithmic bytes)} scaled from the sampled brackets to all of
+    them; synchronises."""
     torch.cuda.synchronize()
-    return {k: (len(v), sum(r[0].elapsed_time(r[1]) for r in v), sum(r[2] for r in v), sum(r[3] for r in v))
-            for k, v in timing.records.items()}
+    out = {}
+    for k, v in timing.records.items():
+        scale = timing.seen.get(k, len(v)) / max(len(v), 1)
+        out[k] = (timing.seen.get(k, len(v)), scale * sum(r[0].elapsed_time(r[1]) for r in v),
+                  scale * sum(r[2] for r in v), scale * sum(r[3] for r in v))
+    return out

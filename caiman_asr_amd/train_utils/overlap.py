@@ -45,6 +45,11 @@ def flush_deferred():
     global _deferred
     if _deferred:
         todo, _deferred = _deferred, []
+        # start behind what the caller has just queued, not next to it: the side streams wait for this point
+        gate = torch.cuda.Event()
+        gate.record(torch.cuda.current_stream())
+        for s in _side.values():
+            s.wait_event(gate)
         for launch in todo:
             launch()
 
