@@ -282,8 +282,9 @@ def main():
             "unit": "audio-hours/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("base-85M RNN-T bf16 training, LibriSpeech-960 shapes, batch 32 per GPU "
-                                    "(BASELINE.json configs[1])") if args.model == "base" else
+            "config": {"workload": (f"base-85M RNN-T bf16 training, LibriSpeech-960 shapes, batch {args.batch} per GPU "
+                                    + ("(BASELINE.json configs[1])" if args.batch == 32 else
+                                       "(per-GPU shape of BASELINE.json configs[2] when 128)")) if args.model == "base" else
                                    "large-196M RNN-T bf16 training + on-GPU SpecAugment (BASELINE.json configs[3] shapes)",
                        "global_batch": args.batch * world, "utterance_seconds": "clip(N(12.3,3.8),1,16.7)",
                        "parallelism": f"dp{world}", "final_loss": loss_val,
