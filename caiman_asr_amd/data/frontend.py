@@ -166,3 +166,70 @@ def norm_ramp_params(norm_type: NormType, warmup_steps, hold_steps, half_life_st
     start = ramp_start if ramp_start is not None else warmup_steps + hold_steps + half_life_steps
     end = ramp_end if ramp_end is not None else start + default_ramp
     return start, end
+
+
+class StreamingFrontend:
+    """The same features for N live audio streams, chunk by chunk (BASELINE configs[4]: "real-time 16 kHz streams").
+
+    `step(audio [N, n])` takes the next n samples of every stream and returns the spliced feature frames they
+    complete, [frames, N, n_filt * stacking] -- what `RNNT.encode` eats.  Carried per stream: the last
+    `win_len - hop + 1` samples (window overlap + the pre-emphasis neighbour; the zeros an utterance starts with are
+    exactly the reference's initial padding, pipeline.py:260-268) and the log-mel frames not yet consumed by the frame
+    splicing.  Normalisation uses dataset statistics, as inference does (the hardware checkpoint ships melmeans /
+    melvars with melalpha = 0, hardware_ckpt.py:150-156); per-utterance statistics do not exist for a live stream.
+    Pre-emphasis runs as one elementwise op on the carried buffer, then the log-mel kernel is called with its own
+    pre-emphasis and padding off.  Chunked output == offline output on the concatenated audio (tests)."""
+
+    def __init__(self, frontend: LogMelFrontend, n_streams: int, mel_means: Optional[torch.Tensor] = None,
+                 mel_stddevs: Optional[torch.Tensor] = None, frame_stacking: int = 3, frame_subsampling: int = 3):
+        assert frontend.initial_pad in (0, frontend.win_len - frontend.hop), "streaming assumes the standard initial padding"
+        self.fe, self.N = frontend, n_streams
+        self.stack, self.sub = frame_stacking, frame_subsampling
+        dev = frontend.window.device
+        self.keep = frontend.win_len - frontend.hop + 1
+        self.tail = torch.zeros(n_streams, self.keep, device=dev)      # zeros = initial padding (+ a zero neighbour)
+        if frontend.initial_pad == 0:
+            self.tail = None                                             # first chunk starts the signal itself
+        self.mean = None if mel_means is None else mel_means.to(dev, torch.float32).view(1, -1, 1)
+        self.istd = None if mel_stddevs is None else (1.0 / mel_stddevs.to(dev, torch.float32)).view(1, -1, 1)
+        self.frames = None        # log-mel frames waiting for the splicer, [N, n_filt, k]
+        self.samples_seen = 0
+
+    @torch.no_grad()
+    def step(self, audio: torch.Tensor) -> Optional[torch.Tensor]:
+        fe = self.fe
+        assert audio.dim() == 2 and audio.shape[0] == self.N and audio.dtype == torch.float32
+        if self.tail is None:    # no initial padding: the very first sample is its own pre-emphasis neighbour
+            buf = torch.cat([audio[:, :1], audio], 1)
+        else:
+            buf = torch.cat([self.tail, audio], 1)
+        self.samples_seen += audio.shape[1]
+        L = buf.shape[1] - 1
+        if L < fe.win_len:
+            self.tail = buf
+            return None
+        n_new = (L - fe.win_len) // fe.hop + 1
+        used = (n_new - 1) * fe.hop + fe.win_len                 # samples of y covered by the new frames
+        y = (buf[:, 1:used + 1] - fe.preemph * buf[:, :used]).contiguous()
+        self.tail = buf[:, n_new * fe.hop:].contiguous()         # overlap for the next frame + the neighbour sample
+        lens = torch.full((self.N,), used, dtype=torch.int32, device=buf.device)
+        out = torch.empty((self.N, fe.n_filt, n_new), dtype=torch.float32, device=buf.device)
+        out_len = torch.empty((self.N,), dtype=torch.int32, device=buf.device)
+        seed = self.samples_seen if fe.dither != 0.0 else 0
+        _lib.check(_lib.lib().caiman_logmel_forward(
+            _lib.ptr(y), _lib.ptr(lens), self.N, used, fe.win_len, fe.hop, fe.n_fft, fe.n_filt, 0, 0.0, fe.dither, seed,
+            1e-20, _lib.ptr(fe.window), _lib.ptr(fe.tw_cos), _lib.ptr(fe.tw_sin), _lib.ptr(fe.mel_w), _lib.ptr(fe.mel_lo),
+            _lib.ptr(fe.mel_hi), _lib.ptr(out), _lib.ptr(out_len), n_new, _lib.stream()))
+        if self.mean is not None:
+            out = (out - self.mean) * self.istd
+        fr = out if self.frames is None else torch.cat([self.frames, out], 2)
+        # splice: output frame j = frames [sub*j, sub*j + stack) stacked on the feature axis
+        n_out = (fr.shape[2] - self.stack) // self.sub + 1 if fr.shape[2] >= self.stack else 0
+        if n_out <= 0:
+            self.frames = fr
+            return None
+        idx = (torch.arange(n_out, device=fr.device) * self.sub).view(-1, 1) + torch.arange(self.stack, device=fr.device)
+        sp = fr[:, :, idx]                                        # [N, F, n_out, stack]
+        sp = sp.permute(2, 0, 3, 1).reshape(n_out, self.N, self.stack * fe.n_filt)   # [stack][F] order = cat over frames
+        self.frames = fr[:, :, n_out * self.sub:]
+        return sp.contiguous()

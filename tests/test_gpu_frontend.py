@@ -95,3 +95,31 @@ def test_hip_frontend_reproduces_the_reference_golden_logmel():
     out = MelFeatNormalizer(None, None, None, None, 0.0, NormType.UTTERANCE_STATS)(out, n)
     err = (out[0].cpu().numpy() - g["logmel_norm"])
     assert np.abs(err).max() < 4e-4 and np.abs(err).mean() < 1e-5
+
+
+@pytest.mark.parametrize("chunk", [960, 400, 1777])
+def test_streaming_frontend_equals_offline(chunk):
+    """Audio fed in chunks with carried state gives the frames of the offline chain (log-mel -> dataset-stats
+    normalisation -> stack 3 / keep every 3rd) on the whole signal, up to the frames the tail has not completed."""
+    from caiman_asr_amd.data.features import stack_subsample_frames
+    from caiman_asr_amd.data.frontend import LogMelFrontend, StreamingFrontend
+
+    n = 16000
+    a = torch.tensor(_audio([n, n, n], seed=4), device=DEV)
+    mean = torch.linspace(-12, -8, 80)
+    std = torch.linspace(1.5, 3.0, 80)
+    fe = LogMelFrontend(dither=0.0, device=DEV)
+    full, full_len = fe(a, torch.tensor([n, n, n]))
+    full = (full - mean.to(DEV).view(1, -1, 1)) / std.to(DEV).view(1, -1, 1)
+    ref, ref_len = stack_subsample_frames(full, full_len, 3, 3)          # [B, 240, T3]
+    sf = StreamingFrontend(fe, 3, mean, std)
+    got = []
+    for t0 in range(0, n, chunk):
+        out = sf.step(a[:, t0:t0 + chunk].contiguous())
+        if out is not None:
+            got.append(out)
+    got = torch.cat(got, 0)                                                 # [frames, B, 240]
+    k = got.shape[0]
+    n_complete = (int(full_len[0]) - 3) // 3 + 1                            # spliced frames whose 3 inputs all exist
+    assert k == n_complete and k >= int(ref_len[0]) - 1
+    assert torch.allclose(got.permute(1, 2, 0), ref[:, :, :k], atol=2e-4, rtol=1e-5)
