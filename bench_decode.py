@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--logit-scale", type=float, default=30.0, help="widen random-init logits so decisions vary")
     ap.add_argument("--max-symbols", type=int, default=8)
     ap.add_argument("--decoder", choices=["greedy", "beam"], default="greedy")
+    ap.add_argument("--no-calibrate", action="store_true", help="greedy: skip the closed-loop emission-rate fit (for profiling)")
     ap.add_argument("--from-audio", action="store_true",
                     help="feed 960 samples (60 ms at 16 kHz) per stream and tick through the streaming log-mel frontend "
                          "instead of ready feature frames")
@@ -194,27 +195,28 @@ def main():
                 set_scale(scale, b)
             return greedy_rate()
 
-        b0, step = blank_shift(scale), max(1.0, 0.5 * scale * float(raw[:, :-1].std()))
-        lo = hi = b0
-        for _ in range(16):
-            if rate(hi) <= args.emit_rate:
-                break
-            lo, hi = hi, hi + step
-            step *= 2
-        for _ in range(16):
-            if lo < hi and rate(lo) > args.emit_rate:
-                break
-            lo -= step
-            step *= 2
-        for _ in range(8):
-            mid = 0.5 * (lo + hi)
-            lo, hi = (mid, hi) if rate(mid) > args.emit_rate else (lo, mid)
-        # the rate can be steep in the bias: settle on the bracket end whose rate is closer to the target
-        import math
+        if not args.no_calibrate:
+            b0, step = blank_shift(scale), max(1.0, 0.5 * scale * float(raw[:, :-1].std()))
+            lo = hi = b0
+            for _ in range(16):
+                if rate(hi) <= args.emit_rate:
+                    break
+                lo, hi = hi, hi + step
+                step *= 2
+            for _ in range(16):
+                if lo < hi and rate(lo) > args.emit_rate:
+                    break
+                lo -= step
+                step *= 2
+            for _ in range(8):
+                mid = 0.5 * (lo + hi)
+                lo, hi = (mid, hi) if rate(mid) > args.emit_rate else (lo, mid)
+            # the rate can be steep in the bias: settle on the bracket end whose rate is closer to the target
+            import math
 
-        ends = [(abs(math.log(max(rate(b), 1e-4) / args.emit_rate)), b) for b in (lo, hi)]
-        best = min(ends)[1]
-        print(f"[bench_decode] blank bias {b0:.2f} -> {best:.2f}: greedy tokens/frame {rate(best):.3f}", file=sys.stderr)
+            ends = [(abs(math.log(max(rate(b), 1e-4) / args.emit_rate)), b) for b in (lo, hi)]
+            best = min(ends)[1]
+            print(f"[bench_decode] blank bias {b0:.2f} -> {best:.2f}: greedy tokens/frame {rate(best):.3f}", file=sys.stderr)
         dec = StreamingGreedyDecoder(model, N_CLASSES - 1, n_streams=args.streams, max_symbols_per_step=args.max_symbols)
     if args.from_audio:
         from caiman_asr_amd.data.frontend import LogMelFrontend, StreamingFrontend

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from caiman_asr_amd import _lib
 from caiman_asr_amd.rnnt.eos_strategy import EOSBlank, EOSIgnore, EOSPredict, EOSStrategy
 from caiman_asr_amd.rnnt.response import DecodingResponse, FrameResponses, HypothesisResponse
 from caiman_asr_amd.rnnt.state import EncoderState
@@ -88,6 +89,33 @@ class RNNTCommonDecoder:
         # normalise BEFORE the EOS strategy so that beta is a probability threshold (decoder.py:161-172)
         return self._eos_prob_correction(F.log_softmax(logits.float() / self.temperature, dim=-1))
 
+    def _joint_best(self, enc, pred):
+        """-> (log-prob, token) of the most probable entry per row: `_joint_step(...).max(-1)` in one pass over the
+        logits (`caiman_beam_topk`, k = 1: temperature, log-softmax, EOS correction and arg-max fused; ties go to the
+        lower id, as torch's max does)."""
+        logits = self.model.joint(enc, pred)[:, 0, 0, :]
+        if not logits.is_cuda or logits.dtype == torch.float64:
+            lp = self._eos_prob_correction(F.log_softmax(logits.float() / self.temperature, dim=-1))
+            return lp.max(-1)
+        if not logits.is_contiguous():
+            logits = logits.contiguous()
+        n, V = logits.shape
+        s = self.eos_strategy
+        mode = (0, 0, 1.0, 0.0)
+        if isinstance(s, EOSIgnore):
+            mode = (1, s.eos_idx, 1.0, 0.0)
+        elif isinstance(s, EOSBlank):
+            mode = (2, s.eos_idx, 1.0, 0.0)
+        elif isinstance(s, EOSPredict):
+            mode = (3, s.eos_idx, float(s.alpha), float(s.beta))
+        score = torch.empty(n, dtype=torch.float32, device=logits.device)
+        token = torch.empty(n, dtype=torch.int32, device=logits.device)
+        blank = torch.empty(n, dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.lib().caiman_beam_topk(_lib.ptr(logits), n, V, logits.stride(0), _lib.dtype_tag(logits.dtype),
+                                               float(self.temperature), self.blank_idx, mode[0], mode[1], mode[2], mode[3],
+                                               1, _lib.ptr(score), _lib.ptr(token), _lib.ptr(blank), _lib.stream()))
+        return score, token.long()
+
 
 class RNNTBatchedGreedyDecoder(RNNTCommonDecoder):
     def __init__(self, model, blank_idx: int, eos_strategy: EOSStrategy, max_inputs_per_batch: int, tokenizer,
@@ -107,8 +135,7 @@ class RNNTBatchedGreedyDecoder(RNNTCommonDecoder):
         blank = self.blank_idx
         idx = st["off"].clamp(max=encs.shape[1] - 1)
         f = torch.gather(encs, 1, idx.view(B, 1, 1).expand(-1, -1, jH))
-        logprobs = self._joint_step(f, st["g"])
-        lp, k = logprobs.max(-1)  # first maximum wins (torch semantics), as in the reference
+        lp, k = self._joint_best(f, st["g"])  # first maximum wins (torch semantics), as in the reference
         at_end = st["off"] == st["max_off"]
         is_blank = k == blank
         # stop rules (batched_greedy.py:168-199): evaluated BEFORE this iteration's emission is counted
@@ -140,6 +167,10 @@ class RNNTBatchedGreedyDecoder(RNNTCommonDecoder):
                 keep(off, st["off"]), advance & active
         st["done"], st["total"], st["per_step"], st["off"] = done, total, per_step, off
         # prediction network: step every row, keep the result where a symbol was emitted
+        if st.get("big") is not None:   # thousands of rows: GEMM + cell kernel, states updated in place where emitted
+            G = st["big"].step(torch.where(emitted, label, torch.zeros_like(label)), emitted)
+            st["g"] = torch.where(emitted.view(B, 1, 1), G.view(B, 1, -1).to(st["g"].dtype), st["g"])
+            return record, advance
         y = torch.where(emitted, label, torch.zeros_like(label)).unsqueeze(1)
         G, (HH, CC), _ = self.model.predict(y, (st["h"], st["c"]), add_sos=False)
         m = emitted.view(1, B, 1)
@@ -148,9 +179,21 @@ class RNNTBatchedGreedyDecoder(RNNTCommonDecoder):
         st["g"] = torch.where(emitted.view(B, 1, 1), G.to(st["g"].dtype), st["g"])
         return record, advance
 
+    LARGE_BATCH = 256   # from this many rows on the prediction step is a library GEMM + the cell kernel
+
     def _initial_state(self, B, device, enc_lens):
-        g, (h, c), _ = self.model.predict(None, None, add_sos=False)  # zero embedding, zero state
         z = lambda: torch.zeros(B, dtype=torch.long, device=device)
+        rnn = self.model.prediction["dec_rnn"]
+        if (B >= self.LARGE_BATCH and torch.device(device).type == "cuda" and hasattr(rnn, "lstm")
+                and not rnn.batch_norm and not getattr(rnn.lstm, "hard", False)):
+            from caiman_asr_amd.rnnt.streaming_lstm import LargeBatchPredictor
+
+            big = LargeBatchPredictor(self.model, B)
+            g = big.step(None, None, dev=device).view(B, 1, -1).clone()   # start of sequence: zero embedding, zero state
+            return {"g": g, "h": None, "c": None, "big": big, "off": z(), "per_step": z(), "total": z(),
+                    "done": torch.zeros(B, dtype=torch.bool, device=device),
+                    "max_off": enc_lens.to(device=device, dtype=torch.long) - 1}
+        g, (h, c), _ = self.model.predict(None, None, add_sos=False)  # zero embedding, zero state
         return {"g": g.expand(B, -1, -1).contiguous(), "h": h.expand(-1, B, -1).contiguous(),
                 "c": c.expand(-1, B, -1).contiguous(), "off": z(), "per_step": z(), "total": z(),
                 "done": torch.zeros(B, dtype=torch.bool, device=device),
@@ -223,17 +266,36 @@ class StreamingEncoder:
     """Encoder of B concurrent streams advanced chunk by chunk: pre-rnn with carried (h, c), StackTime over a
     carried remainder of pre-rnn frames, post-rnn with carried (h, c), joint_enc projection."""
 
-    def __init__(self, model, n_streams: int):
+    LARGE_BATCH = 256   # from this many streams on, a timestep of a layer is a library GEMM + the cell kernel
+
+    def __init__(self, model, n_streams: int, large_batch: Optional[bool] = None):
         self.model = getattr(model, "module", model)
         self.B = n_streams
         self.enc_state: Optional[EncoderState] = None
         self.carry = None  # pre-rnn output frames not yet consumed by StackTime
+        self.big = None
+        if large_batch if large_batch is not None else n_streams >= self.LARGE_BATCH:
+            from caiman_asr_amd.rnnt.streaming_lstm import LargeBatchLSTM
+
+            self.big = (LargeBatchLSTM(self.model.encoder["pre_rnn"], n_streams),
+                        LargeBatchLSTM(self.model.encoder["post_rnn"], n_streams))
 
     @torch.no_grad()
     def advance(self, feats: torch.Tensor) -> Optional[torch.Tensor]:
         """feats [n, B, in_feats] -> encoder frames completed by this chunk, [B, n_enc, Hj], or None."""
         m, B = self.model, self.B
         factor = m.enc_stack_time_factor
+        if self.big is not None:      # states live inside the two LargeBatchLSTM objects
+            x = self.big[0].forward(feats)
+            if self.carry is not None:
+                x = torch.cat([self.carry, x], 0)
+            n_full = (x.shape[0] // factor) * factor
+            self.carry = x[n_full:] if n_full < x.shape[0] else None
+            if n_full == 0:
+                return None
+            xs = x[:n_full].view(n_full // factor, factor, B, -1).transpose(1, 2).reshape(n_full // factor, B, -1)
+            y = self.big[1].forward(xs)
+            return m.joint_enc(y.transpose(0, 1))
         x, pre_state, _ = m.encoder["pre_rnn"](feats, self.enc_state.pre_rnn if self.enc_state else None)
         if self.carry is not None:
             x = torch.cat([self.carry, x], 0)

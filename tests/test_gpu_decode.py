@@ -254,3 +254,49 @@ def test_streaming_beam_stragglers_catch_up():
     assert tk0 == tk1 and ts0 == ts1 and keys0 == keys1
     for a, b in zip(cf0, cf1):
         assert np.allclose(a, b, atol=1e-4)
+
+
+def test_large_batch_streaming_encoder_equals_module_path():
+    """The GEMM + cell-kernel encoder step used for thousands of streams gives the frames of the step-kernel path."""
+    from caiman_asr_amd.rnnt.decoder import StreamingEncoder
+
+    g, m = build("mfma")
+    torch.manual_seed(11)
+    T, B = 12, 7
+    x = torch.randn(T, B, g["x"].shape[2], device=DEV)
+    a, b = StreamingEncoder(m, B, large_batch=False), StreamingEncoder(m, B, large_batch=True)
+    fa, fb = [], []
+    for t0, n in ((0, 2), (2, 3), (5, 1), (6, 4), (10, 2)):       # odd chunk sizes exercise the StackTime carry
+        ya, yb = a.advance(x[t0:t0 + n]), b.advance(x[t0:t0 + n])
+        assert (ya is None) == (yb is None)
+        if ya is not None:
+            fa.append(ya)
+            fb.append(yb)
+    fa, fb = torch.cat(fa, 1), torch.cat(fb, 1)
+    assert fa.shape == fb.shape == (B, T // 2, fa.shape[2])
+    assert torch.allclose(fa, fb, atol=2e-5, rtol=1e-5)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a, b = StreamingEncoder(m, B, large_batch=False), StreamingEncoder(m, B, large_batch=True)
+        ya, yb = a.advance(x[:4]), b.advance(x[:4])
+    assert torch.allclose(ya.float(), yb.float(), atol=3e-2, rtol=3e-2)
+
+
+def test_greedy_large_batch_predictor_equals_module_path(monkeypatch):
+    """The GEMM + cell-kernel prediction step (used from 256 rows on) decodes the same tokens as the module path."""
+    from caiman_asr_amd.rnnt.decoder import RNNTBatchedGreedyDecoder, flatten_responses
+
+    g, m = build("mfma")
+    V = int(g["n_classes"])
+    torch.manual_seed(2)
+    T, B = 20, 9
+    x = torch.randn(T, B, g["x"].shape[2], device=DEV)
+    lens = torch.tensor([20, 18, 20, 7, 20, 13, 20, 20, 2], device=DEV)
+    out = []
+    for thresh in (10 ** 9, 1):
+        monkeypatch.setattr(RNNTBatchedGreedyDecoder, "LARGE_BATCH", thresh)
+        dec = RNNTBatchedGreedyDecoder(m, V - 1, None, int(1e7), None, max_symbols_per_step=3)
+        out.append(flatten_responses(dec.decode(x, lens)))
+    (tk0, ts0, cf0), (tk1, ts1, cf1) = out
+    assert tk0 == tk1 and ts0 == ts1 and sum(map(len, tk0)) > 10
+    for a, b in zip(cf0, cf1):
+        assert np.allclose(a, b, atol=1e-4)
