@@ -40,7 +40,7 @@ def main():
                          "instead of ready feature frames")
     ap.add_argument("--beam-width", type=int, default=4)
     ap.add_argument("--top1-prob", type=float, default=0.85,
-                    help="beam: mean top-1 probability of softmax(logits/1.4) the synthetic logits are scaled to (0 = keep --logit-scale)")
+                    help="mean top-1 probability of softmax(logits/T) the synthetic logits are scaled to (0 = keep --logit-scale)")
     ap.add_argument("--straggler-frac", type=float, default=0.01,
                     help="beam: a tick ends once a round serves no more than this fraction of the streams; they catch up later")
     ap.add_argument("--tick-budget-ms", type=float, default=40.0,
@@ -82,15 +82,16 @@ def main():
             return torch.quantile(margin, 1.0 - args.emit_rate).item()
 
         scale = args.logit_scale
-        if args.decoder == "beam" and args.top1_prob > 0:
+        temp = 1.4 if args.decoder == "beam" else 1.0
+        if args.top1_prob > 0:
             # a trained transducer is confident: first guess of the scale at which the mean top-1 probability of
-            # softmax(logits / 1.4) is `top1_prob` (bisection on the probe; refined closed-loop below)
+            # softmax(logits / T) is `top1_prob` (bisection on the probe; beam: refined closed-loop below)
             lo, hi = 1.0, 1e7
             for _ in range(40):
                 scale = (lo * hi) ** 0.5
                 z = scale * raw
                 z[:, -1] += blank_shift(scale)
-                top1 = torch.softmax(z / 1.4, -1).max(-1).values.mean().item()
+                top1 = torch.softmax(z / temp, -1).max(-1).values.mean().item()
                 lo, hi = (scale, hi) if top1 < args.top1_prob else (lo, scale)
         W0, B0 = model.joint_net[2].weight.detach().clone(), model.joint_net[2].bias.detach().clone()
 
