@@ -112,8 +112,8 @@ def main():
         pieces = ["<unk>"] + [("\u2581" if i % 3 == 0 else "") + "".join(letters[(i // 26 ** d) % 26] for d in range(3))
                               for i in range(1, N_CLASSES - 1)]
 
-        def new_decoder(n, cutoff=0):
-            return StreamingBeamDecoder(model, N_CLASSES - 1, n, pieces, beam_width=args.beam_width,
+        def new_decoder(n, cutoff=0, raw=False):
+            return StreamingBeamDecoder(model, N_CLASSES - 1, n, pieces, beam_width=args.beam_width, raw_responses=raw,
                                         max_symbols_per_step=args.max_symbols, temperature=1.4, straggler_cutoff=cutoff,
                                         max_expansions_per_frame=args.max_expansions,
                                         tick_budget_s=args.tick_budget_ms * 1e-3 if cutoff else None)
@@ -176,7 +176,7 @@ def main():
                 scale /= 1.8
         else:
             fit_blank_bias(scale)
-        dec = new_decoder(args.streams, cutoff=int(args.straggler_frac * args.streams))
+        dec = new_decoder(args.streams, cutoff=int(args.straggler_frac * args.streams), raw=True)   # records, not Python objects
     else:
         # closed loop on short greedy decodes: bisect the blank bias until `emit_rate` tokens per frame are emitted
         def greedy_rate(n=256, ticks=40, settle=20):
@@ -247,8 +247,8 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = dec.step(next_feats(i))
-            if args.decoder == "beam":   # responses are host objects already
-                n_tok = sum(len(r.final.alternatives[0].y_seq) for per in out for r in per.values() if r.final)
+            if args.decoder == "beam":   # the flat response records are on the host already
+                n_tok = dec.search.count_final_tokens(out[0], len(out[1]))
                 n_frames = 1
             else:
                 n_tok = sum(int(n.sum().item()) for _, n in out)  # results on the host = end of the tick
@@ -269,7 +269,8 @@ def main():
                 frames += n_frames * args.streams
     if args.decoder == "beam":   # what the best hypotheses still hold
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            tokens += sum(len(r.final.alternatives[0].y_seq) for per in dec.close() for r in per.values() if r.final)
+            last = dec.close()
+            tokens += dec.search.count_final_tokens(last[0], len(last[1]))
     lat.sort()
     p50, p99, worst = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.99 * len(lat)))], lat[-1]
     if args.decoder == "beam" and args.profile_host:

@@ -126,15 +126,39 @@ class NativeBeamSearch:
     def state_slots(self) -> int:
         return int(self.L.caiman_beam_state_slots(self.h))
 
-    def take_responses(self) -> List[Dict[int, FrameResponses]]:
-        """Responses since the last call -> per stream {frame key: FrameResponses}."""
+    def take_raw_responses(self):
+        """Responses since the last call as the library's flat records (include/caiman_beam.h): (ints i32, floats f32)
+        numpy copies.  What a server forwards without building Python objects; `count_final_tokens` reads them."""
         ip, fp = _I32P(), ctypes.POINTER(ctypes.c_float)()
         ni, nf = ctypes.c_int64(), ctypes.c_int64()
         self._check(self.L.caiman_beam_responses(self.h, ctypes.byref(ip), ctypes.byref(ni), ctypes.byref(fp),
                                                  ctypes.byref(nf)))
-        ints = np.ctypeslib.as_array(ip, (ni.value,)).tolist() if ni.value else []
-        flts = np.ctypeslib.as_array(fp, (nf.value,)).tolist() if nf.value else []
+        ints = np.ctypeslib.as_array(ip, (ni.value,)).copy() if ni.value else np.zeros(0, np.int32)
+        flts = np.ctypeslib.as_array(fp, (nf.value,)).copy() if nf.value else np.zeros(0, np.float32)
         self.L.caiman_beam_clear_responses(self.h)
+        return ints, flts
+
+    @staticmethod
+    def count_final_tokens(ints: np.ndarray, n_floats: int, has_partials: bool = False) -> int:
+        """Tokens in the final records of a raw response block.  Without partials every confidence belongs to a
+        final, so the count is the length of the float array; with partials the record headers are walked."""
+        if not has_partials:
+            return int(n_floats)
+        i, total, n = 0, 0, len(ints)
+        while i < n:
+            kind, n_alt = int(ints[i + 2]), int(ints[i + 5])
+            i += 6
+            for _ in range(n_alt):
+                k = int(ints[i])
+                if kind == 0:
+                    total += k
+                i += 1 + 2 * k
+        return total
+
+    def take_responses(self) -> List[Dict[int, FrameResponses]]:
+        """Responses since the last call -> per stream {frame key: FrameResponses}."""
+        ints, flts = self.take_raw_responses()
+        ints, flts = ints.tolist(), flts.tolist()
         out: List[Dict[int, FrameResponses]] = [dict() for _ in range(self.n_streams)]
         i = f = 0
         while i < len(ints):
@@ -381,7 +405,8 @@ class StreamingBeamDecoder:
     later ticks.  `backlog()` reports the lag."""
 
     def __init__(self, model, blank_idx: int, n_streams: int, sentpiece_model: Union[str, Sequence[str]],
-                 straggler_cutoff: int = 0, ring: int = 32, tick_budget_s: Optional[float] = None, **kwargs):
+                 straggler_cutoff: int = 0, ring: int = 32, tick_budget_s: Optional[float] = None,
+                 raw_responses: bool = False, **kwargs):
         self.dec = RNNTBeamDecoderNative(model, blank_idx, kwargs.pop("eos_strategy", None), sentpiece_model, **kwargs)
         self.model = self.dec.model
         self.B = n_streams
@@ -389,6 +414,7 @@ class StreamingBeamDecoder:
         self.search = NativeBeamSearch(n_streams, **self.dec.search_args)
         self.all_streams = np.arange(n_streams, dtype=np.int32)
         self.straggler_cutoff, self.ring, self.tick_budget_s = straggler_cutoff, ring, tick_budget_s
+        self.raw_responses = raw_responses   # step() returns the flat records instead of FrameResponses objects
         self.frames = None        # [ring, N, Hj] the most recent encoder frames
         self.n_frames = 0
         self.rounds = 0
@@ -410,7 +436,7 @@ class StreamingBeamDecoder:
             torch.cuda.synchronize()
             prof["encoder"] += time.perf_counter() - t0
         if f_all is None:
-            return [dict() for _ in range(self.B)]
+            return (np.zeros(0, np.int32), np.zeros(0, np.float32)) if self.raw_responses else [dict() for _ in range(self.B)]
         if self.frames is None:
             self.frames = torch.zeros(self.ring, self.B, f_all.shape[-1], device=f_all.device, dtype=f_all.dtype)
         for j in range(f_all.shape[1]):
@@ -422,7 +448,7 @@ class StreamingBeamDecoder:
             self.rounds += self.dec._rounds(self.search, self.frames.view(self.ring * self.B, -1), self._rows_of,
                                             stop_below=cutoff, deadline=deadline)
         t0 = time.perf_counter()
-        out = self.search.take_responses()
+        out = self.search.take_raw_responses() if self.raw_responses else self.search.take_responses()
         if prof is not None:
             prof["responses"] += time.perf_counter() - t0
         return out
@@ -432,4 +458,4 @@ class StreamingBeamDecoder:
             self.rounds += self.dec._rounds(self.search, self.frames.view(self.ring * self.B, -1), self._rows_of)
         for b in range(self.B):
             self.search.close_stream(b)
-        return self.search.take_responses()
+        return self.search.take_raw_responses() if self.raw_responses else self.search.take_responses()
