@@ -10,6 +10,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <mutex>
@@ -214,43 +215,112 @@ class Workers {
 };
 
 // ---- hypothesis (hypothesis.py:38-162) -----------------------------------------------------------------
+// One entry per non-blank token that has not been shipped yet: id, frame, confidence.  Entry 0 is a sentinel (SOS = -1,
+// or the last shipped token).  The reference keeps a fourth list with the piece strings; a piece is a function of
+// the id (the sentinel -1 stands for the text "▁"), so it is not stored.
+struct Tok {
+  int32_t y, ts;
+  float p;
+};
+
+// Short sequences live inside the hypothesis (no heap traffic when a hypothesis is cloned, which happens about five
+// times per expansion); finals keep them short.
+class Seq {
+ public:
+  static constexpr uint32_t kInline = 12;
+  Seq() = default;
+  Seq(const Seq& o) : n_(o.n_) {
+    if (o.n_ <= kInline) {
+      std::memcpy(inl_, o.data(), o.n_ * sizeof(Tok));
+    } else {
+      cap_ = o.n_ + kInline;
+      heap_ = static_cast<Tok*>(std::malloc(cap_ * sizeof(Tok)));
+      std::memcpy(heap_, o.data(), o.n_ * sizeof(Tok));
+    }
+  }
+  Seq& operator=(const Seq&) = delete;
+  ~Seq() { std::free(heap_); }
+  uint32_t size() const { return n_; }
+  const Tok* data() const { return heap_ ? heap_ : inl_; }
+  const Tok& operator[](uint32_t i) const { return data()[i]; }
+  const Tok& back() const { return data()[n_ - 1]; }
+  void push_back(Tok t) {
+    if (n_ == cap_) {
+      cap_ *= 2;
+      Tok* nh = static_cast<Tok*>(std::malloc(cap_ * sizeof(Tok)));
+      std::memcpy(nh, data(), n_ * sizeof(Tok));
+      std::free(heap_);
+      heap_ = nh;
+    }
+    mut()[n_++] = t;
+  }
+  void drop_front(uint32_t k) {
+    std::memmove(mut(), data() + k, (n_ - k) * sizeof(Tok));
+    n_ -= k;
+  }
+
+ private:
+  Tok* mut() { return heap_ ? heap_ : inl_; }
+  Tok inl_[kInline];
+  Tok* heap_ = nullptr;
+  uint32_t n_ = 0, cap_ = kInline;
+};
+
 struct Hyp {
   double score = 0.0;
-  std::vector<float> p;     // confidences
-  std::vector<int32_t> y;   // token ids; [0] is a sentinel (SOS or the last shipped token)
-  std::vector<int32_t> ts;  // frame of each token
-  std::vector<int32_t> s;   // piece ids (text of each token)
+  Seq seq;
   int32_t y_len_t = 0;
   uint64_t hash = 0;
   int32_t slot = -1;
   bool terminal = false;
   int64_t prev_len = 0;
-  Keywords::State kws = Keywords::init();
+  Keywords::State kws;  // empty = the start state {0: 0.0} (only materialised when keywords are configured)
   SlotPool* pool;
 
   explicit Hyp(SlotPool* pl) : pool(pl) {}
   Hyp(const Hyp& o)
-      : score(o.score), p(o.p), y(o.y), ts(o.ts), s(o.s), y_len_t(o.y_len_t), hash(o.hash), slot(o.slot),
-        terminal(o.terminal), prev_len(o.prev_len), kws(o.kws), pool(o.pool) {
+      : score(o.score), seq(o.seq), y_len_t(o.y_len_t), hash(o.hash), slot(o.slot), terminal(o.terminal),
+        prev_len(o.prev_len), kws(o.kws), pool(o.pool) {
     pool->retain(slot);
   }
   Hyp& operator=(const Hyp&) = delete;
   ~Hyp() { pool->release(slot); }
+
+  // hypotheses are created and destroyed by the million: recycle their blocks per thread
+  static std::vector<void*>& block_cache() {
+    struct Holder {
+      std::vector<void*> v;
+      ~Holder() { for (void* p : v) ::operator delete(p); }
+    };
+    static thread_local Holder h;
+    return h.v;
+  }
+  static void* operator new(size_t sz) {
+    auto& c = block_cache();
+    if (!c.empty()) {
+      void* p = c.back();
+      c.pop_back();
+      return p;
+    }
+    return ::operator new(sz);
+  }
+  static void operator delete(void* p) {
+    auto& c = block_cache();
+    if (c.size() < 8192) c.push_back(p);
+    else ::operator delete(p);
+  }
 
   void set_slot(int32_t ns) {
     pool->retain(ns);
     pool->release(slot);
     slot = ns;
   }
-  int64_t len_tot() const { return (int64_t)y.size() + prev_len; }
+  int64_t len_tot() const { return (int64_t)seq.size() + prev_len; }
   double norm_score() const { return score / (double)len_tot(); }
   void truncate(size_t tkn_idx) {
     const size_t cut = tkn_idx - 1;
     prev_len += (int64_t)cut;
-    p.erase(p.begin(), p.begin() + cut);
-    y.erase(y.begin(), y.begin() + cut);
-    ts.erase(ts.begin(), ts.begin() + cut);
-    s.erase(s.begin(), s.begin() + cut);
+    seq.drop_front((uint32_t)cut);
   }
   void update_hash(const uint32_t* cps, size_t n) {
     for (size_t i = 0; i < n; ++i) hash = (hash * kMaxUnicode + cps[i]) % kHashSize;
@@ -339,23 +409,20 @@ struct caiman_beam {
   // ---- text helpers --------------------------------------------------------------------------------
   const Piece& piece(int32_t id) const { return id == kSosPiece ? sos_piece : pieces[id]; }
   int cmp_sseq(const Hyp& a, const Hyp& b) const {  // Python list-of-str comparison
-    const size_t n = std::min(a.s.size(), b.s.size());
+    const size_t n = std::min(a.seq.size(), b.seq.size());
     for (size_t i = 0; i < n; ++i) {
-      if (a.s[i] == b.s[i]) continue;
-      const int c = piece(a.s[i]).utf8.compare(piece(b.s[i]).utf8);
+      if (a.seq[i].y == b.seq[i].y) continue;
+      const int c = piece(a.seq[i].y).utf8.compare(piece(b.seq[i].y).utf8);
       if (c != 0) return c;
     }
-    return a.s.size() < b.s.size() ? -1 : a.s.size() > b.s.size() ? 1 : 0;
+    return a.seq.size() < b.seq.size() ? -1 : a.seq.size() > b.seq.size() ? 1 : 0;
   }
   bool same_piece(int32_t a, int32_t b) const { return a == b || piece(a).utf8 == piece(b).utf8; }
 
   // ---- set helpers ------------------------------------------------------------------------------------
   HypPtr sos_hyp() {
     HypPtr h(new Hyp(&pool));
-    h->p = {1.0f};
-    h->y = {-1};
-    h->ts = {-1};
-    h->s = {kSosPiece};
+    h->seq.push_back({kSosPiece, -1, 1.0f});
     h->y_len_t = 1;
     return h;
   }
@@ -383,12 +450,13 @@ struct caiman_beam {
     auto& o = out().i;
     o.insert(o.end(), {stream, (int32_t)key, kind, (int32_t)start, (int32_t)dur, n_alt});
   }
-  void emit_alt(const int32_t* y, const int32_t* ts, const float* p, size_t n) {
+  // tokens [1, 1 + n) of a hypothesis; `frames` overrides its own frame indices when given
+  void emit_alt(const Hyp& h, size_t n, const int32_t* frames = nullptr) {
     Out& o = out();
     o.i.push_back((int32_t)n);
-    o.i.insert(o.i.end(), y, y + n);
-    o.i.insert(o.i.end(), ts, ts + n);
-    o.f.insert(o.f.end(), p, p + n);
+    for (size_t i = 0; i < n; ++i) o.i.push_back(h.seq[1 + i].y);
+    for (size_t i = 0; i < n; ++i) o.i.push_back(frames ? frames[i] : h.seq[1 + i].ts);
+    for (size_t i = 0; i < n; ++i) o.f.push_back(h.seq[1 + i].p);
   }
   // run fn(stream index in `list`) over a list of streams, on the worker threads when the list is long
   template <typename F>
@@ -416,14 +484,14 @@ struct caiman_beam {
     const size_t n = tkn_idx - 1;
     std::vector<int32_t> frames(n);
     for (size_t i = 0; i < n; ++i) {
-      int32_t m = head.ts[1 + i];
-      for (const Hyp* h : hyps) m = std::min(m, h->ts[1 + i]);
+      int32_t m = head.seq[1 + i].ts;
+      for (const Hyp* h : hyps) m = std::min(m, h->seq[1 + i].ts);
       frames[i] = m;
     }
     const int32_t lo = *std::min_element(frames.begin(), frames.end());
     const int32_t hi = *std::max_element(frames.begin(), frames.end());
     emit_header(stream, key, 0, lo, hi - lo + 1, 1);
-    emit_alt(head.y.data() + 1, frames.data(), head.p.data() + 1, n);
+    emit_alt(head, n, frames.data());
   }
   // -> true if a final was shipped (and the shared prefix cut off every hypothesis)
   bool get_final(int32_t stream, int64_t key, HypSet* kept) {
@@ -431,9 +499,9 @@ struct caiman_beam {
     for (auto& h : kept->v) sorted.push_back(h.get());
     std::stable_sort(sorted.begin(), sorted.end(), [&](const Hyp* a, const Hyp* b) { return cmp_sseq(*a, *b) < 0; });
     const Hyp &first = *sorted.front(), &last = *sorted.back();
-    const size_t lim = std::min(first.s.size(), last.s.size());
+    const size_t lim = std::min(first.seq.size(), last.seq.size());
     size_t k = 1;
-    while (k < lim && same_piece(first.s[k], last.s[k])) ++k;
+    while (k < lim && same_piece(first.seq[k].y, last.seq[k].y)) ++k;
     if (k == 1) return false;
     emit_final(stream, key, sorted, k);
     for (auto& h : kept->v) h->truncate(k);
@@ -444,18 +512,18 @@ struct caiman_beam {
     int64_t start = key;
     int n_alt = 0;
     for (const Hyp* h : order)
-      if (h->ts.size() > 1) {
+      if (h->seq.size() > 1) {
         ++n_alt;
-        start = std::min<int64_t>(start, *std::min_element(h->ts.begin() + 1, h->ts.end()));
+        for (uint32_t i = 1; i < h->seq.size(); ++i) start = std::min<int64_t>(start, h->seq[i].ts);
       }
     emit_header(stream, key, 1, start, key - start + 1, n_alt);
     for (const Hyp* h : order)
-      if (h->ts.size() > 1) emit_alt(h->y.data() + 1, h->ts.data() + 1, h->p.data() + 1, h->y.size() - 1);
+      if (h->seq.size() > 1) emit_alt(*h, h->seq.size() - 1);
   }
   void last_frame_response(int32_t stream, int64_t key, const HypSet& kept) {  // serialise_responses.py:58-75
     const Hyp* best = nbest(kept)[0];
-    if (best->y.size() > 1)
-      emit_final(stream, key, {best}, best->y.size());
+    if (best->seq.size() > 1)
+      emit_final(stream, key, {best}, best->seq.size());
     else
       emit_header(stream, key, 2, key, 0, 0);
   }
@@ -487,7 +555,7 @@ struct caiman_beam {
   bool silence_terminate(const HypSet& kept, int64_t idx) const {  // beam.py:266-283
     if (cfg.eos_vad_threshold == kInf) return false;
     int32_t last = std::numeric_limits<int32_t>::min();
-    for (auto& h : kept.v) last = std::max(last, h->ts.back());
+    for (auto& h : kept.v) last = std::max(last, h->seq.back().ts);
     if (last < 0) return false;
     return (double)(idx - last) * cfg.frame_width >= cfg.eos_vad_threshold;
   }
@@ -518,7 +586,7 @@ struct caiman_beam {
       }
       if (shipped) {
         int32_t m = std::numeric_limits<int32_t>::max();
-        for (auto& h : s.kept.v) m = std::min(m, h->ts[0]);
+        for (auto& h : s.kept.v) m = std::min(m, h->seq[0].ts);
         s.last_final_idx = m;
         break;
       }
@@ -556,18 +624,19 @@ struct caiman_beam {
     }
     HypPtr h(new Hyp(parent));
     h->score += logp;
-    h->p.push_back(std::exp(logp_f));
-    h->ts.push_back((int32_t)time_idx);
+    const int32_t prev_tok = h->seq.back().y;
+    h->seq.push_back({tok, (int32_t)time_idx, std::exp(logp_f)});
     h->set_slot(out_slot);
-    h->y.push_back(tok);
     h->y_len_t += 1;
     if (cfg.eos_terminal_idx >= 0 && tok == cfg.eos_terminal_idx) h->terminal = true;
     const Piece& pc = pieces[tok];
-    h->score += keywords.steps(pc.cps, &h->kws);
+    if (keywords.children.size() > 1) {
+      if (h->kws.empty()) h->kws = Keywords::init();
+      h->score += keywords.steps(pc.cps, &h->kws);
+    }
     // a word-boundary mark right after a word-boundary mark adds nothing to the text (beam.py:644-659)
-    const Piece& prev = piece(h->s.back());
+    const Piece& prev = piece(prev_tok);
     const bool doubled = !prev.cps.empty() && prev.cps.back() == kSpu && pc.cps[0] == kSpu;
-    h->s.push_back(tok);
     h->update_hash(pc.cps.data() + (doubled ? 1 : 0), pc.cps.size() - (doubled ? 1 : 0));
     const int i = s.open.find(h->hash);
     if (i < 0) {
@@ -743,7 +812,7 @@ extern "C" int64_t caiman_beam_requests(caiman_beam_t* h, int32_t* stream, int32
   for (int32_t si : live) {
     auto& s = h->streams[si];
     s.cur_out_slot = h->pool.acquire();
-    h->pending.push_back({si, (int32_t)s.t, s.cur->y.back(), s.cur->slot, s.cur_out_slot});
+    h->pending.push_back({si, (int32_t)s.t, s.cur->seq.back().y, s.cur->slot, s.cur_out_slot});
   }
   for (size_t i = 0; i < h->pending.size(); ++i) {
     const Request& r = h->pending[i];
