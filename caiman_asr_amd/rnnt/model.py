@@ -56,6 +56,7 @@ class RNNT(nn.Module):
             "joint_pred": joint_pred_lr_factor, "joint_net": joint_net_lr_factor}
         self.pred_n_hid = pred_n_hid
         self.enc_stack_time_factor = enc_stack_time_factor
+        self.encoder_pipe = True    # one layer pipeline across pre_rnn / StackTime / post_rnn when the stacks allow it
         # opt-in: joint_fc's weight gradient runs on a side stream (train_utils/overlap.py); the training
         # loop must call overlap.wait_all() before it reads the gradients
         self.overlap_weight_grads = False
@@ -154,8 +155,35 @@ class RNNT(nn.Module):
         out = self.joint(f, g, x_lens, g_lens, batch_offset, packed_batch=packed_batch)
         return out, x_lens, new_state
 
+    def _encode_one_pipeline(self, x, x_lens, enc_state):
+        """pre_rnn -> StackTime -> post_rnn as ONE layer pipeline (rnnt_ext/custom_lstm/encoder_pipe.py), or None when
+        the configuration is not covered (then the stacks run one after the other)."""
+        pre, post = self.encoder["pre_rnn"], self.encoder["post_rnn"]
+        if not (self.encoder_pipe and getattr(pre, "using_custom_lstm", False) and not pre.batch_norm
+                and not post.batch_norm):
+            return None
+        from caiman_asr_amd.rnnt_ext.custom_lstm import encoder_pipe as ep
+
+        a, b, f = pre.lstm, post.lstm, self.enc_stack_time_factor
+        gate_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        if not (ep.eligible(x, a.hidden_size, a.num_layers, b.num_layers, gate_dtype, f) and a.hidden_size == b.hidden_size
+                and a.hard == b.hard and a.rw_dropout == 0.0 and b.rw_dropout == 0.0 and a.bl_dropout == b.bl_dropout
+                and a.pipeline_layers and b.pipeline_layers):
+            return None
+        y, all_pre, all_post = ep.encoder_pipe(x, a, b, f, enc_state.pre_rnn if enc_state else None,
+                                               enc_state.post_rnn if enc_state else None)
+        if post.dropout:
+            y = post.dropout(y)
+        return y, (x_lens.int() + f - 1) // f, all_pre, all_post
+
     def encode(self, x, x_lens, enc_state: Optional[EncoderState] = None):
         """x [T,B,I], x_lens [B] -> f [B,T',Hj], lens', EncoderState|None."""
+        merged = self._encode_one_pipeline(x, x_lens, enc_state)
+        if merged is not None:
+            y, lens2, all_pre, all_post = merged
+            pre_last = maybe_get_last_nonpadded(all_pre, x_lens)
+            post_last = maybe_get_last_nonpadded(all_post, lens2)
+            return self.joint_enc(y.transpose(0, 1)), lens2, EncoderState(pre_rnn=pre_last, post_rnn=post_last)
         x, _, all_pre = self.encoder["pre_rnn"](x, enc_state.pre_rnn if enc_state else None)
         pre_last = maybe_get_last_nonpadded(all_pre, x_lens)
         x, x_lens = self.encoder["stack_time"](x, x_lens)

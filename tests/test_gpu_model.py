@@ -340,3 +340,65 @@ def test_optimizer_state_and_ema_checkpoint_roundtrip(tmp_path):
     opt.step()
     opt2.step()
     assert torch.equal(opt2.flat_p, opt.flat_p)
+
+
+@pytest.mark.parametrize("T1, factor", [(75, 2), (64, 2), (33, 2), (70, 3)])
+def test_encoder_one_pipeline_equals_two_stacks(T1, factor):
+    """pre_rnn -> StackTime -> post_rnn as ONE layer pipeline (encoder_pipe.py): same outputs, final states and
+    gradients as the stack-after-stack schedule (bf16 rounding of differently chunked GEMMs aside)."""
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    torch.manual_seed(0)
+    kw = dict(n_classes=29, in_feats=48, enc_n_hid=64, enc_pre_rnn_layers=2, enc_post_rnn_layers=3,
+              enc_stack_time_factor=factor, enc_dropout=0.0, enc_batch_norm=False, pred_n_hid=32, pred_rnn_layers=1,
+              pred_dropout=0.0, pred_batch_norm=False, joint_n_hid=48, joint_dropout=0.0, forget_gate_bias=1.0,
+              custom_lstm=True)
+    m = RNNT(**kw).to(DEV)
+    B = 5
+    x = torch.randn(T1, B, 48, device=DEV)
+    lens = torch.tensor([T1, T1 - 3, T1 // 2, 7, T1], device=DEV)
+    outs = []
+    for pipe in (False, True):
+        m.encoder_pipe = pipe
+        m.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            f, f_lens, st = m.encode(xi, lens)
+        w = torch.linspace(0.5, 1.5, f.numel(), device=DEV).view_as(f)
+        (f.float() * w).sum().backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None and n.startswith("encoder")}
+        outs.append((f.float(), f_lens, st, xi.grad.clone(), grads))
+    (f0, l0, s0, dx0, g0), (f1, l1, s1, dx1, g1) = outs
+    assert torch.equal(l0, l1) and f0.shape == f1.shape
+    assert torch.allclose(f0, f1, atol=2e-2 * float(f0.abs().max()), rtol=0)
+    for a, b in ((s0.pre_rnn, s1.pre_rnn), (s0.post_rnn, s1.post_rnn)):
+        for u, v in zip(a, b):
+            assert torch.allclose(u.float(), v.float(), atol=2e-2, rtol=0)
+    assert torch.allclose(dx0, dx1, atol=3e-2 * float(dx0.abs().max()), rtol=0)
+    assert set(g0) == set(g1) and len(g0) == 20
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], atol=3e-2 * float(g0[n].abs().max()) + 1e-6, rtol=0), n
+
+
+def test_encoder_one_pipeline_with_dropout_trains():
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    torch.manual_seed(0)
+    m = RNNT(n_classes=29, in_feats=48, enc_n_hid=64, enc_pre_rnn_layers=2, enc_post_rnn_layers=3, enc_stack_time_factor=2,
+             enc_dropout=0.3, enc_batch_norm=False, pred_n_hid=32, pred_rnn_layers=1, pred_dropout=0.0, pred_batch_norm=False,
+             joint_n_hid=48, joint_dropout=0.0, forget_gate_bias=1.0, custom_lstm=True).to(DEV).train()
+    m.encoder_pipe = True
+    x = torch.randn(70, 4, 48, device=DEV, requires_grad=True)
+    lens = torch.tensor([70, 60, 33, 70], device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        f1, _, _ = m.encode(x, lens)
+        f2, _, _ = m.encode(x, lens)
+    assert not torch.equal(f1, f2)                       # fresh masks per call
+    f1.float().square().mean().backward()
+    assert torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+    assert all(torch.isfinite(p.grad).all() for n, p in m.named_parameters() if n.startswith("encoder"))
+    m.eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        e1, _, _ = m.encode(x, lens)
+        e2, _, _ = m.encode(x, lens)
+    assert torch.equal(e1, e2)
