@@ -22,7 +22,7 @@ from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 from caiman_asr_amd.rnnt_ext.custom_lstm import stack
 from caiman_asr_amd.rnnt_ext.custom_lstm.stack import INTERLEAVED, _pad32, _perm_rows, _Scratch, _unperm_rows
 
-CH = 32
+CH = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_CHUNK", "32"))   # timesteps per pipeline chunk
 
 
 def eligible(x, hidden, La, Lb, gate_dtype, factor):
