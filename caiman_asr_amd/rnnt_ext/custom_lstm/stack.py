@@ -26,7 +26,14 @@ CHUNK = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK", "32"))  # timestep
 CHUNK_DEEP = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK_DEEP", "32"))  # stacks of >= 4 layers
 
 
-def _chunk(L):
+CHUNK_SHORT = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK_SHORT", "8"))  # sequences of <= 128 steps
+
+
+def _chunk(L, T=None):
+    """A short sequence (the prediction network sees ~60 tokens) pays the (L-1)-chunk pipeline fill relatively
+    more: smaller chunks there (measured 38.3 -> 38.1 ms per step), 32 otherwise."""
+    if T is not None and T <= 128:
+        return CHUNK_SHORT
     return CHUNK_DEEP if L >= 4 else CHUNK
 # opt-in (set by the training loop): weight gradients are computed on the side stream and added straight into
 # `param.grad` (train_utils/overlap.py); the loop must call overlap.wait_all() before reading gradients.
@@ -109,7 +116,7 @@ class StackFunction(torch.autograd.Function):
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]), _lib.ptr(ring[l]),
                                                 None, B, H, tag, 0, INTERLEAVED, st))
-        CH = _chunk(L)
+        CH = _chunk(L, T)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), False)
         row = B * H
@@ -183,7 +190,7 @@ class StackFunction(torch.autograd.Function):
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
                                                 B, H, tag, 1, INTERLEAVED, st))
-        CH = _chunk(L)
+        CH = _chunk(L, T)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), True)
         for tau in range(n_ch + L - 1):
