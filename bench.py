@@ -116,7 +116,8 @@ def main():
                          "deadlocks were seen at batch 64+ where more streams share the hardware queues, so it is opt-in)")
     ap.add_argument("--no-overlap", action="store_true", help="(default now; kept so that old command lines still parse)")
     ap.add_argument("--encoder-pipe", type=int, default=1,
-                    help="1: pre_rnn -> StackTime -> post_rnn as one layer pipeline (encoder_pipe.py); 0: stack after stack")
+                    help="1: pre_rnn -> StackTime -> post_rnn as one layer pipeline (encoder_pipe.py); 2: with the prediction "
+                         "network's steps in the same launches (measured: 38.58 vs 38.55 ms, no gain); 0: stack after stack")
     ap.add_argument("--main-priority", type=int, default=0,
                     help="run the step on a stream of this priority (-1 = above the side streams; 0 = the default stream; measured: no effect)")
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
@@ -159,7 +160,8 @@ def main():
         args.no_cpu_baseline = True  # the CPU sample is defined on the base config
     model = RNNT(n_classes=N_CLASSES, **rnnt_cfg).to(dev)
     model.train()
-    model.encoder_pipe = bool(args.encoder_pipe)
+    model.encoder_pipe = args.encoder_pipe >= 1
+    model.pred_in_encoder_pipe = args.encoder_pipe >= 2
     model.overlap_weight_grads = args.overlap and not args.no_overlap
     model.parallel_prediction = args.overlap and not args.no_overlap
     from caiman_asr_amd.rnnt_ext.custom_lstm import stack as lstm_stack

@@ -74,7 +74,7 @@ class FwdSlot(ctypes.Structure):
     _fields_ = [("weights_tiled", ctypes.c_void_p), ("gates", ctypes.c_void_p), ("c", ctypes.c_void_p),
                 ("y", ctypes.c_void_p), ("ring", ctypes.c_void_p), ("parity", ctypes.c_int32),
                 ("nsteps", ctypes.c_int32), ("y_masked", ctypes.c_void_p), ("drop_counter", ctypes.c_uint64),
-                ("drop_p", ctypes.c_float), ("reserved", ctypes.c_int32)]
+                ("drop_p", ctypes.c_float), ("hidden", ctypes.c_int32)]
 
 
 class BwdSlot(ctypes.Structure):
@@ -82,7 +82,8 @@ class BwdSlot(ctypes.Structure):
                 ("delta", ctypes.c_void_p), ("delta_stride_t", ctypes.c_int64), ("delta_stride_b", ctypes.c_int64),
                 ("dG", ctypes.c_void_p), ("ring", ctypes.c_void_p), ("dC", ctypes.c_void_p),
                 ("parity", ctypes.c_int32), ("nsteps", ctypes.c_int32), ("has_next", ctypes.c_int32),
-                ("drop_p", ctypes.c_float), ("drop_counter", ctypes.c_uint64)]
+                ("drop_p", ctypes.c_float), ("drop_counter", ctypes.c_uint64), ("hidden", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 class BeamConfig(ctypes.Structure):
     """caiman_beam_config_t (include/caiman_beam.h)."""

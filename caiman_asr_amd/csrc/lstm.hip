@@ -230,6 +230,7 @@ struct FwdSlots {
   T* ymask[kMaxSlots];
   uint64_t drop_base[kMaxSlots];
   float drop_p[kMaxSlots];
+  int hidden[kMaxSlots];  // 0: the launch's H; otherwise this slot's own (smaller) hidden size
   uint64_t seed;
 };
 
@@ -250,6 +251,7 @@ struct BwdSlots {
   // keep/scale the forward applied (drop_p == 0: delta is used as is); counter of row t_hi's first element
   uint64_t drop_base[kMaxSlots];
   float drop_p[kMaxSlots];
+  int hidden[kMaxSlots];  // as in FwdSlots
   uint64_t seed;
 };
 
@@ -260,11 +262,13 @@ struct BwdSlots {
 // [B, 4, H]: the epilogue then moves one 8-byte vector per (row, unit) instead of four 2-byte elements a
 // whole H apart (PMC: the scattered form fetched ~40 % more HBM bytes than the algorithmic count).
 template <typename T, bool HARD, int NK, bool IL>
-__global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int step, int B, int H) {
+__global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int step, int B, int H_launch) {
   using frag = typename frag8<T>::type;
   __shared__ float tile[4][2][16][17];
   const int slot = blockIdx.z;
   if (step >= w.nsteps[slot]) return;
+  const int H = w.hidden[slot] ? w.hidden[slot] : H_launch;   // slots of one launch may differ in width
+  if ((int)blockIdx.x * 4 >= H) return;
   const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
   const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
   const T* __restrict__ Rtile = w.Rtile[slot];
@@ -377,11 +381,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_mfma(FwdSlots<T> w, int ste
 // ---- backward step: grid (H/16, ceil(B/32), slots), 1024 threads = 16 waves ---------------------
 //   dh tile: 32 batch rows x 16 hidden units, K = 4H dealt round-robin to the 16 waves.
 template <typename T, bool HARD, int NK, bool IL>
-__global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int step, int B, int H) {
+__global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int step, int B, int H_launch) {
   using frag = typename frag8<T>::type;
   __shared__ float tile[16][2][16][17];
   const int slot = blockIdx.z;
   if (step >= w.nsteps[slot]) return;
+  const int H = w.hidden[slot] ? w.hidden[slot] : H_launch;
+  if ((int)blockIdx.x * 16 >= H) return;
   const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
   const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
   const T* __restrict__ Rttile = w.Rttile[slot];
@@ -695,6 +701,9 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
       w.y[i] = (T*)slots[i].y; w.hring[i] = (T*)slots[i].ring; w.parity[i] = slots[i].parity & 1;
       w.nsteps[i] = slots[i].nsteps;
       w.ymask[i] = (T*)slots[i].y_masked; w.drop_base[i] = slots[i].drop_counter; w.drop_p[i] = slots[i].drop_p;
+      CAIMAN_CHECK(slots[i].hidden == 0 || (slots[i].hidden >= 32 && slots[i].hidden % 32 == 0 && slots[i].hidden <= H),
+                   "lstm_wave_fwd: slot %d hidden size must be 0 or a multiple of 32 not above H", i);
+      w.hidden[i] = slots[i].hidden;
       CAIMAN_CHECK(slots[i].drop_p >= 0.f && slots[i].drop_p < 1.f, "lstm_wave_fwd: dropout p must be in [0,1)");
     }
     w.seed = seed;
@@ -730,6 +739,9 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
       w.parity[i] = slots[i].parity & 1; w.nsteps[i] = slots[i].nsteps; w.has_in0[i] = slots[i].has_next ? 1 : 0;
       w.drop_base[i] = slots[i].drop_counter; w.drop_p[i] = slots[i].drop_p;
       CAIMAN_CHECK(slots[i].drop_p >= 0.f && slots[i].drop_p < 1.f, "lstm_wave_bwd: dropout p must be in [0,1)");
+      CAIMAN_CHECK(slots[i].hidden == 0 || (slots[i].hidden >= 32 && slots[i].hidden % 32 == 0 && slots[i].hidden <= H),
+                   "lstm_wave_bwd: slot %d hidden size must be 0 or a multiple of 32 not above H", i);
+      w.hidden[i] = slots[i].hidden;
     }
     w.seed = seed;
     if (gate_layout)

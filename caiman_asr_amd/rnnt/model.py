@@ -57,6 +57,7 @@ class RNNT(nn.Module):
         self.pred_n_hid = pred_n_hid
         self.enc_stack_time_factor = enc_stack_time_factor
         self.encoder_pipe = True    # one layer pipeline across pre_rnn / StackTime / post_rnn when the stacks allow it
+        self.pred_in_encoder_pipe = False  # opt-in: the prediction network's LSTM steps in the same launches (measured: no gain)
         # opt-in: joint_fc's weight gradient runs on a side stream (train_utils/overlap.py); the training
         # loop must call overlap.wait_all() before it reads the gradients
         self.overlap_weight_grads = False
@@ -101,6 +102,10 @@ class RNNT(nn.Module):
     # ---- forward pieces -------------------------------------------------------
     def enc_pred(self, x, x_lens, y, y_lens, pred_net_state: Optional[PredNetState] = None,
                  enc_state: Optional[EncoderState] = None):
+        if self.encoder_pipe and self.pred_in_encoder_pipe and x.is_cuda:
+            out = self._enc_pred_one_pipeline(x, x_lens, y, y_lens, pred_net_state, enc_state)
+            if out is not None:
+                return out
         if not (self.parallel_prediction and x.is_cuda):
             return self.enc_pred_static(x, x_lens, y, y_lens, self.encode, self.predict,
                                         pred_net_state=pred_net_state, enc_state=enc_state)
@@ -117,6 +122,33 @@ class RNNT(nn.Module):
         if new_enc_state is not None and new_pred is not None:
             rnnt_state = RNNTState(enc_state=new_enc_state, pred_net_state=new_pred)
         return (f, x_lens), (g, g_lens), rnnt_state
+
+    def _enc_pred_one_pipeline(self, x, x_lens, y, y_lens, pred_net_state, enc_state):
+        """Encoder and prediction network in the same LSTM launches (encoder_pipe.py); None if not covered."""
+        y = label_collate(y)
+        emb = self.prediction["embed"](y)                       # predict(): embedding, SOS row in front
+        Bn, _, E = emb.shape
+        if pred_net_state is None:
+            start = torch.zeros((Bn, 1, E), device=emb.device, dtype=emb.dtype)
+        else:
+            start = self.prediction["embed"](pred_net_state.last_token).to(device=emb.device, dtype=emb.dtype)
+        pred_in = torch.cat([start, emb], dim=1).transpose(0, 1).contiguous()
+        merged = self._encode_one_pipeline(x, x_lens, enc_state, pred_in=pred_in,
+                                           pred_state=pred_net_state.next_to_last_pred_state if pred_net_state else None)
+        if merged is None:
+            return None
+        yt, lens2, all_pre, all_post, yp, all_pred = merged
+        dec = self.prediction["dec_rnn"]
+        if dec.dropout:
+            yp = dec.dropout(yp)
+        f = self.joint_enc(yt.transpose(0, 1))
+        g = self.joint_pred(yp.transpose(0, 1))
+        g_lens = y_lens + 1
+        new_enc = EncoderState(pre_rnn=maybe_get_last_nonpadded(all_pre, x_lens),
+                               post_rnn=maybe_get_last_nonpadded(all_post, lens2))
+        new_pred = get_pred_net_state(y, all_pred, y_lens, g_lens)
+        state = RNNTState(enc_state=new_enc, pred_net_state=new_pred) if new_pred is not None else None
+        return (f, lens2), (g, g_lens), state
 
     def _predict_on_side_stream(self, *args, **kwargs):
         """The prediction network does not depend on the encoder: run it (forward, and through autograd its
@@ -155,9 +187,10 @@ class RNNT(nn.Module):
         out = self.joint(f, g, x_lens, g_lens, batch_offset, packed_batch=packed_batch)
         return out, x_lens, new_state
 
-    def _encode_one_pipeline(self, x, x_lens, enc_state):
+    def _encode_one_pipeline(self, x, x_lens, enc_state, pred_in=None, pred_state=None):
         """pre_rnn -> StackTime -> post_rnn as ONE layer pipeline (rnnt_ext/custom_lstm/encoder_pipe.py), or None when
-        the configuration is not covered (then the stacks run one after the other)."""
+        the configuration is not covered (then the stacks run one after the other).  With `pred_in` [U+1, B, E] the
+        prediction network's LSTM steps ride in the same launches (None is returned if it cannot)."""
         pre, post = self.encoder["pre_rnn"], self.encoder["post_rnn"]
         if not (self.encoder_pipe and getattr(pre, "using_custom_lstm", False) and not pre.batch_norm
                 and not post.batch_norm):
@@ -170,17 +203,28 @@ class RNNT(nn.Module):
                 and a.hard == b.hard and a.rw_dropout == 0.0 and b.rw_dropout == 0.0 and a.bl_dropout == b.bl_dropout
                 and a.pipeline_layers and b.pipeline_layers):
             return None
-        y, all_pre, all_post = ep.encoder_pipe(x, a, b, f, enc_state.pre_rnn if enc_state else None,
-                                               enc_state.post_rnn if enc_state else None)
+        p = None
+        if pred_in is not None:
+            dec = self.prediction["dec_rnn"]
+            if not getattr(dec, "using_custom_lstm", False) or dec.batch_norm:
+                return None
+            p = dec.lstm
+            if not (p.hidden_size % 32 == 0 and p.hidden_size <= a.hidden_size and p.hard == a.hard and p.rw_dropout == 0.0
+                    and p.pipeline_layers and a.num_layers + b.num_layers + p.num_layers <= 8
+                    and pred_in.shape[1] == x.shape[1]):
+                return None
+        y, all_pre, all_post, yp, all_pred = ep.encoder_pipe(
+            x, a, b, f, enc_state.pre_rnn if enc_state else None, enc_state.post_rnn if enc_state else None,
+            pred=p, xp=pred_in, pred_state=pred_state)
         if post.dropout:
             y = post.dropout(y)
-        return y, (x_lens.int() + f - 1) // f, all_pre, all_post
+        return y, (x_lens.int() + f - 1) // f, all_pre, all_post, yp, all_pred
 
     def encode(self, x, x_lens, enc_state: Optional[EncoderState] = None):
         """x [T,B,I], x_lens [B] -> f [B,T',Hj], lens', EncoderState|None."""
         merged = self._encode_one_pipeline(x, x_lens, enc_state)
         if merged is not None:
-            y, lens2, all_pre, all_post = merged
+            y, lens2, all_pre, all_post, _, _ = merged
             pre_last = maybe_get_last_nonpadded(all_pre, x_lens)
             post_last = maybe_get_last_nonpadded(all_post, lens2)
             return self.joint_enc(y.transpose(0, 1)), lens2, EncoderState(pre_rnn=pre_last, post_rnn=post_last)

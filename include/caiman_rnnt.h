@@ -151,13 +151,16 @@ int caiman_lstm_fused_bwd(const void* R, const void* gates, const void* c, const
 typedef struct {
   const void* weights_tiled; void* gates; void* c; void* y; void* ring;
   int32_t parity; int32_t nsteps;
-  void* y_masked; uint64_t drop_counter; float drop_p; int32_t reserved;
+  void* y_masked; uint64_t drop_counter; float drop_p;
+  int32_t hidden; /* 0: the call's H.  Otherwise this slot's own hidden size (a multiple of 32, <= H): slots of
+                     different width can share a launch (prediction network next to the encoder) */
 } caiman_lstm_fwd_slot_t;
 typedef struct {
   const void* weights_tiled; const void* gates; const void* c; const void* delta;
   int64_t delta_stride_t; int64_t delta_stride_b; void* dG; void* ring; void* dC;
   int32_t parity; int32_t nsteps; int32_t has_next; float drop_p;
   uint64_t drop_counter;
+  int32_t hidden; int32_t reserved; /* hidden: as in the forward slot */
 } caiman_lstm_bwd_slot_t;
 /* gate_layout: 0 = the reference's gates / dG layout [B, 4, H] (gate-major, lstm.cu:99-102);
  *              1 = interleaved [B, H, 4] (the 4 gates of a hidden unit adjacent): an internal layout of the

@@ -402,3 +402,41 @@ def test_encoder_one_pipeline_with_dropout_trains():
         e1, _, _ = m.encode(x, lens)
         e2, _, _ = m.encode(x, lens)
     assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("pred_layers, pred_hid, U", [(2, 32, 37), (1, 64, 5), (2, 64, 70)])
+def test_prediction_network_rides_in_the_encoder_launches(pred_layers, pred_hid, U):
+    """enc_pred with the prediction LSTM's steps in the encoder pipeline's launches (slots of their own hidden size)
+    == encoder and prediction network run separately: outputs, carried states, gradients."""
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    torch.manual_seed(1)
+    m = RNNT(n_classes=29, in_feats=48, enc_n_hid=64, enc_pre_rnn_layers=2, enc_post_rnn_layers=3, enc_stack_time_factor=2,
+             enc_dropout=0.0, enc_batch_norm=False, pred_n_hid=pred_hid, pred_rnn_layers=pred_layers, pred_dropout=0.0,
+             pred_batch_norm=False, joint_n_hid=48, joint_dropout=0.0, forget_gate_bias=1.0, custom_lstm=True).to(DEV)
+    T1, B = 75, 5
+    x = torch.randn(T1, B, 48, device=DEV)
+    lens = torch.tensor([T1, T1 - 3, T1 // 2, 7, T1], device=DEV)
+    y = torch.randint(0, 28, (B, U), device=DEV)
+    y_lens = torch.tensor([U, max(U - 2, 1), 1, max(U // 2, 1), U], device=DEV)
+    outs = []
+    for pipe in (False, True):
+        m.encoder_pipe = m.pred_in_encoder_pipe = pipe
+        m.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            (f, f_lens), (g, g_lens), st = m.enc_pred(xi, lens, y, y_lens)
+        (f.float().square().sum() + (g.float() * torch.linspace(0.5, 1.5, g.numel(), device=DEV).view_as(g)).sum()).backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        outs.append((f.float(), g.float(), f_lens, g_lens, st, xi.grad.clone(), grads))
+    (f0, g0, fl0, gl0, s0, dx0, gr0), (f1, g1, fl1, gl1, s1, dx1, gr1) = outs
+    assert torch.equal(fl0, fl1) and torch.equal(gl0, gl1)
+    assert torch.allclose(f0, f1, atol=2e-2 * float(f0.abs().max()), rtol=0)
+    assert torch.allclose(g0, g1, atol=2e-2 * float(g0.abs().max()), rtol=0)
+    for a, b in zip(s0.pred_net_state.next_to_last_pred_state, s1.pred_net_state.next_to_last_pred_state):
+        assert torch.allclose(a.float(), b.float(), atol=2e-2, rtol=0)
+    assert torch.equal(s0.pred_net_state.last_token, s1.pred_net_state.last_token)
+    assert torch.allclose(dx0, dx1, atol=3e-2 * float(dx0.abs().max()), rtol=0)
+    assert set(gr0) == set(gr1)
+    for n in gr0:
+        assert torch.allclose(gr0[n], gr1[n], atol=3e-2 * float(gr0[n].abs().max()) + 1e-6, rtol=0), n
