@@ -26,6 +26,16 @@ CH = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_CHUNK", "32"))   # timest
 # post_rnn chunks of CH / factor steps: a post chunk then needs exactly one pre chunk, every post layer works in every
 # tick (for CH / factor launches) and the pipeline drains in half the launches; costs smaller input GEMMs
 FINE = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_FINE", "1")) != 0
+# the chunk GEMMs of the post layers that are active in one tick have the same shape and sit at a constant stride in
+# the activation tensors (layer m works one chunk behind layer m-1): issue them as ONE batched GEMM
+BMM = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_BMM", "1")) != 0
+
+
+def _skewed(t, first_layer, first_t0, count, n, B, width, chunk, row_offset=0):
+    """View [count, n*B, width] of t [layers, steps(+row_offset), B, width]: layer first_layer+i at steps
+    [first_t0 - i*chunk, ... + n) -- the operands of `count` consecutive layers of one tick."""
+    return torch.as_strided(t, (count, n * B, width), (t.stride(0) - chunk * B * width, width, 1),
+                            t[first_layer, row_offset + first_t0].storage_offset())
 
 
 def eligible(x, hidden, La, Lb, gate_dtype, factor):
@@ -148,12 +158,27 @@ class EncoderPipeFunction(torch.autograd.Function):
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), False) if h else 0 for h in Hl]
+        Wt_post = torch.stack([Wp[l].t() for l in range(La + 1, Le)]) if (BMM and Lb > 2) else None      # [Lb-1, H, 4H]
+        b_post = torch.stack([bias[l] for l in range(La + 1, Le)]).unsqueeze(1) if Wt_post is not None else None
         for tick in _schedule(nA, nB, La, Lb, f, nP, Lp):
             slots, nbytes = [], 0
+            batched = set()
+            if Wt_post is not None:   # post layers La+1.. with a full chunk this tick: consecutive layers, chunk index falling by one
+                grp = [(l, k) for l, k in tick if La < l < Le and Tl[l] - k * CHb >= CHb]
+                if len(grp) >= 2 and all(grp[i + 1][0] == grp[i][0] + 1 and grp[i + 1][1] == grp[i][1] - 1 for i in range(len(grp) - 1)):
+                    l0, k0 = grp[0]
+                    m0, cnt = l0 - La, len(grp)
+                    if pl[l0 - 1] > 0.0:
+                        X = _skewed(YMb, m0 - 1, k0 * CHb, cnt, CHb, B, H, CHb)
+                    else:
+                        X = _skewed(Yb, m0 - 1, k0 * CHb, cnt, CHb, B, H, CHb, row_offset=1)
+                    out = _skewed(Gb, m0, k0 * CHb, cnt, CHb, B, 4 * H, CHb)
+                    torch.baddbmm(b_post[m0 - 1:m0 - 1 + cnt], X, Wt_post[m0 - 1:m0 - 1 + cnt], out=out)
+                    batched = {l for l, _ in grp}
             for l, k in tick:
                 t0, n = k * CHl[l], min(CHl[l], Tl[l] - k * CHl[l])
                 hl, row = Hl[l], B * Hl[l]
-                first = l == 0 or l == Le                       # first layer of a chain: whole-sequence input GEMM above
+                first = l == 0 or l == Le or l in batched        # first layer of a chain: whole-sequence input GEMM above
                 if not first:   # input GEMM of this chunk on what the layer below has produced
                     if l == La:
                         src_all = YM[l - 1] if pl[l - 1] > 0.0 else Y[l - 1][1:]
@@ -245,8 +270,19 @@ class EncoderPipeFunction(torch.autograd.Function):
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), True) if h else 0 for h in Hl]
         boundary_done = set()   # post chunks whose input gradient has been un-stacked into delta[La-1]
+        W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]) if (BMM and Lb > 2) else None      # [Lb-1, 4H, H]
         for tick in reversed(_schedule(nA, nB, La, Lb, f, nP, Lp)):
             slots, nbytes = [], 0
+            batched = set()
+            if W_post is not None:   # delta of post layers La..Le-2 with a full chunk: dG of the layer above times its W_ih
+                grp = [(l, k) for l, k in tick if La <= l < Le - 1 and Tl[l] - k * CHb >= CHb]
+                if len(grp) >= 2 and all(grp[i + 1][0] == grp[i][0] + 1 and grp[i + 1][1] == grp[i][1] - 1 for i in range(len(grp) - 1)):
+                    l0, k0 = grp[0]
+                    m0, cnt = l0 - La, len(grp)
+                    X = _skewed(dGb, m0 + 1, k0 * CHb, cnt, CHb, B, 4 * H, CHb)
+                    out = _skewed(delta_b, m0, k0 * CHb, cnt, CHb, B, H, CHb)
+                    torch.bmm(X, W_post[m0:m0 + cnt], out=out)
+                    batched = {l for l, _ in grp}
             for l, k in reversed(tick):
                 t0, n = k * CHl[l], min(CHl[l], Tl[l] - k * CHl[l])
                 thi, hl, row = t0 + n - 1, Hl[l], B * Hl[l]
@@ -257,7 +293,7 @@ class EncoderPipeFunction(torch.autograd.Function):
                         p0, pn = j * CHb, min(CHb, T2 - j * CHb)
                         dx2 = torch.matmul(dG[La][p0:p0 + pn].view(pn * B, 4 * H), Wp[La])       # [pn*B, f*H]
                         delta[l][f * p0:f * (p0 + pn)].view(pn, f, B, H).copy_(dx2.view(pn, B, f, H).transpose(1, 2))
-                elif l not in top:   # dX = dG_{l+1} @ W_{l+1} of the same chunk
+                elif l not in top and l not in batched:   # dX = dG_{l+1} @ W_{l+1} of the same chunk
                     torch.matmul(dG[l + 1][t0:t0 + n].view(n * B, 4 * hl), Wp[l + 1], out=delta[l][t0:t0 + n].view(n * B, hl))
                 d = delta[l]
                 p_slot = pl[l] if l not in top else 0.0
