@@ -155,3 +155,37 @@ def test_mel_filterbank_tables():
     area = w.sum(1) * (16000 / 512)
     assert np.allclose(area[5:], 1.0, atol=0.12)
     assert np.allclose(hann_window(400), of._hann_dali(400))
+
+
+def test_encoder_pipeline_schedule_respects_dependencies():
+    """encoder_pipe._schedule (host logic of the whole-encoder layer pipeline): every (layer, chunk) once, each after
+    the chunks it depends on, never more slots per launch than the kernels accept."""
+    import importlib
+
+    ep = importlib.import_module("caiman_asr_amd.rnnt_ext.custom_lstm.encoder_pipe")
+    CH = ep.CH
+    for fine in (True, False):
+        ep.FINE = fine
+        for T1, La, Lb, f, Tp, Lp in [(430, 2, 6, 2, 0, 0), (75, 2, 3, 2, 0, 0), (33, 1, 1, 2, 0, 0), (70, 2, 3, 3, 0, 0),
+                                      (557, 2, 6, 2, 0, 0), (430, 2, 4, 2, 58, 2), (1, 2, 6, 2, 1, 2), (64, 3, 5, 1, 0, 0)]:
+            T2 = -(-T1 // f)
+            CHb = ep._post_chunk(f)
+            nA, nB, nP = -(-T1 // CH), -(-T2 // CHb), -(-Tp // CH) if Lp else 0
+            ticks = ep._schedule(nA, nB, La, Lb, f, nP, Lp)
+            when = {}
+            for t, tick in enumerate(ticks):
+                assert 1 <= len(tick) <= 8
+                for lk in tick:
+                    assert lk not in when
+                    when[lk] = t
+            assert len(when) == La * nA + Lb * nB + Lp * nP
+            for (l, k), t in when.items():
+                if k > 0:
+                    assert when[(l, k - 1)] < t                              # time order within a layer
+                if 0 < l < La or La < l < La + Lb or l > La + Lb:
+                    assert when[(l - 1, k)] < t                              # the layer below, same chunk
+                if l == La:                                                  # first post layer: the pre chunks it stacks
+                    lo, hi = f * k * CHb, min(f * (k * CHb + min(CHb, T2 - k * CHb)), T1)
+                    for c in range(lo // CH, -(-hi // CH)):
+                        assert when[(La - 1, c)] < t
+    ep.FINE = True
