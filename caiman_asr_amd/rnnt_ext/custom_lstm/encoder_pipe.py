@@ -29,6 +29,7 @@ FINE = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_FINE", "1")) != 0
 # the chunk GEMMs of the post layers that are active in one tick have the same shape and sit at a constant stride in
 # the activation tensors (layer m works one chunk behind layer m-1): issue them as ONE batched GEMM
 BMM = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_BMM", "1")) != 0
+EARLY_WGRAD = int(__import__("os").environ.get("CAIMAN_EARLY_WGRAD", "1")) != 0
 
 
 def _skewed(t, first_layer, first_t0, count, n, B, width, chunk, row_offset=0):
@@ -205,6 +206,7 @@ class EncoderPipeFunction(torch.autograd.Function):
         if drop_p > 0.0:
             saved += [YMp]
         ctx.save_for_backward(*saved)
+        ctx.params = params
         ctx.meta = (L, La, Lb, f, T1, T2, Tp, B, H, Hp, hard, pl, seed, x.requires_grad, Lp and xp.requires_grad, base, flags)
         y_top = Yb[Lb - 1, 1:]
         all_h_a, all_c_a, all_h_b, all_c_b = Ya[:, 1:T1 + 1], Ca[:, 1:], Yb[:, 1:], Cb[:, 1:]
@@ -324,13 +326,25 @@ class EncoderPipeFunction(torch.autograd.Function):
             p = l - Le
             return (YMp[p - 1] if pl[l - 1] > 0.0 else Yp[p - 1, 1:]).reshape(Tp * B, Hp)
 
-        grads = []
-        for l in range(L):
+        # Data-parallel runs: every layer's backward ends in the last few ticks, so nothing can be reduced earlier --
+        # but the ~3 ms of weight-gradient GEMMs that follow can hide the collectives.  With a gradient reducer listening
+        # (train_utils/overlap.py callbacks) each layer's gradients go into `.grad` as soon as they exist, top layers
+        # first (the reducer cuts its buckets from the tail of the arena), and autograd gets None for them.
+        early = EARLY_WGRAD and bool(overlap._grad_ready_callbacks)
+        per_layer = [None] * L
+        for l in (reversed(range(L)) if early else range(L)):
             T, hl = Tl[l], Hl[l]
             dg = dG[l].reshape(T * B, 4 * hl)
             yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
             dB = _unperm_rows(dg.sum(0), hl)
-            grads += [_unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl), _unperm_rows(torch.matmul(dg.t(), yprev), hl), dB, dB]
+            g4 = [_unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl), _unperm_rows(torch.matmul(dg.t(), yprev), hl), dB, dB]
+            if early:
+                for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], g4):
+                    if p_.requires_grad:
+                        overlap._accumulate(p_, g_)
+                g4 = [None] * 4
+            per_layer[l] = g4
+        grads = [g for g4 in per_layer for g in g4]
         dX = torch.matmul(dG[0].reshape(T1 * B, 4 * H), Wp[0]).view(T1, B, -1) if need_dx else None
         dXp = torch.matmul(dG[Le].reshape(Tp * B, 4 * Hp), Wp[Le]).view(Tp, B, -1) if (Lp and need_dxp) else None
         return (dX, None, None, None, None, None, None, None, None, None, None, dXp, None, None, None, *grads)
