@@ -331,13 +331,33 @@ class EncoderPipeFunction(torch.autograd.Function):
         # (train_utils/overlap.py callbacks) each layer's gradients go into `.grad` as soon as they exist, top layers
         # first (the reducer cuts its buckets from the tail of the arena), and autograd gets None for them.
         early = EARLY_WGRAD and bool(overlap._grad_ready_callbacks)
+
+        def unperm_b(w):   # _unperm_rows for a stack of matrices / vectors: [n, 4h(, K)] with rows [unit][gate] -> [gate][unit]
+            n, r = w.shape[0], w.shape[1]
+            return w.reshape(n, r // 4, 4, *w.shape[2:]).transpose(1, 2).reshape(w.shape)
+
+        # post layers have identical shapes: their recurrent-weight gradients (all Lb), their input-weight gradients
+        # (layers 1..Lb-1) and all bias gradients are three batched calls instead of 3 * Lb
+        post_R = post_W = post_b = None
+        if BMM and Lb > 1:
+            dgb = dGb.view(Lb, T2 * B, 4 * H)
+            post_R = unperm_b(torch.bmm(dgb.transpose(1, 2), Yb[:, :T2].reshape(Lb, T2 * B, H)))
+            xin = (YMb[:Lb - 1] if pl[La] > 0.0 else Yb[:Lb - 1, 1:]).reshape(Lb - 1, T2 * B, H)
+            post_W = unperm_b(torch.bmm(dgb[1:].transpose(1, 2), xin))
+            post_b = unperm_b(dgb.sum(1))
         per_layer = [None] * L
         for l in (reversed(range(L)) if early else range(L)):
             T, hl = Tl[l], Hl[l]
             dg = dG[l].reshape(T * B, 4 * hl)
-            yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
-            dB = _unperm_rows(dg.sum(0), hl)
-            g4 = [_unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl), _unperm_rows(torch.matmul(dg.t(), yprev), hl), dB, dB]
+            m = l - La
+            if post_R is not None and 0 <= m < Lb:
+                dB = post_b[m]
+                gW = post_W[m - 1] if m >= 1 else _unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl)
+                g4 = [gW, post_R[m], dB, dB]
+            else:
+                yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
+                dB = _unperm_rows(dg.sum(0), hl)
+                g4 = [_unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl), _unperm_rows(torch.matmul(dg.t(), yprev), hl), dB, dB]
             if early:
                 for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], g4):
                     if p_.requires_grad:
