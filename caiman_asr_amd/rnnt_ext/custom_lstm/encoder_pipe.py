@@ -330,39 +330,52 @@ class EncoderPipeFunction(torch.autograd.Function):
         # but the ~3 ms of weight-gradient GEMMs that follow can hide the collectives.  With a gradient reducer listening
         # (train_utils/overlap.py callbacks) each layer's gradients go into `.grad` as soon as they exist, top layers
         # first (the reducer cuts its buckets from the tail of the arena), and autograd gets None for them.
-        early = EARLY_WGRAD and bool(overlap._grad_ready_callbacks)
+        # Weight gradients leave this function by being ADDED into `param.grad` (a view of the optimiser's fp32 arena),
+        # un-permuting the gate rows and widening to fp32 in that one kernel, instead of being returned: autograd would
+        # add them anyway, after a separate un-permute copy and a cast.  Listeners (the data-parallel reducer,
+        # train_utils/overlap.py) are told per parameter, top layers first: every layer's backward ends in the last
+        # few ticks, so nothing can be reduced earlier than here, but the collectives then run under the remaining
+        # weight-gradient GEMMs.
+        direct = EARLY_WGRAD
 
-        def unperm_b(w):   # _unperm_rows for a stack of matrices / vectors: [n, 4h(, K)] with rows [unit][gate] -> [gate][unit]
-            n, r = w.shape[0], w.shape[1]
-            return w.reshape(n, r // 4, 4, *w.shape[2:]).transpose(1, 2).reshape(w.shape)
+        def deliver(param, g, hl):
+            """g: gradient with rows in the pipeline's [unit][gate] order -> param.grad (rows [gate][unit])."""
+            if not param.requires_grad:
+                return
+            if param.grad is None:
+                param.grad = torch.zeros_like(param)
+            param.grad.view(4, hl, *param.shape[1:]).add_(g.view(hl, 4, *g.shape[1:]).transpose(0, 1))
+            for cb in overlap._grad_ready_callbacks:
+                cb(param)
 
         # post layers have identical shapes: their recurrent-weight gradients (all Lb), their input-weight gradients
         # (layers 1..Lb-1) and all bias gradients are three batched calls instead of 3 * Lb
         post_R = post_W = post_b = None
         if BMM and Lb > 1:
             dgb = dGb.view(Lb, T2 * B, 4 * H)
-            post_R = unperm_b(torch.bmm(dgb.transpose(1, 2), Yb[:, :T2].reshape(Lb, T2 * B, H)))
+            post_R = torch.bmm(dgb.transpose(1, 2), Yb[:, :T2].reshape(Lb, T2 * B, H))
             xin = (YMb[:Lb - 1] if pl[La] > 0.0 else Yb[:Lb - 1, 1:]).reshape(Lb - 1, T2 * B, H)
-            post_W = unperm_b(torch.bmm(dgb[1:].transpose(1, 2), xin))
-            post_b = unperm_b(dgb.sum(1))
+            post_W = torch.bmm(dgb[1:].transpose(1, 2), xin)
+            post_b = dgb.sum(1)
         per_layer = [None] * L
-        for l in (reversed(range(L)) if early else range(L)):
+        for l in (reversed(range(L)) if direct else range(L)):
             T, hl = Tl[l], Hl[l]
             dg = dG[l].reshape(T * B, 4 * hl)
             m = l - La
             if post_R is not None and 0 <= m < Lb:
                 dB = post_b[m]
-                gW = post_W[m - 1] if m >= 1 else _unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl)
+                gW = post_W[m - 1] if m >= 1 else torch.matmul(dg.t(), layer_input(l))
                 g4 = [gW, post_R[m], dB, dB]
             else:
                 yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
-                dB = _unperm_rows(dg.sum(0), hl)
-                g4 = [_unperm_rows(torch.matmul(dg.t(), layer_input(l)), hl), _unperm_rows(torch.matmul(dg.t(), yprev), hl), dB, dB]
-            if early:
+                dB = dg.sum(0)
+                g4 = [torch.matmul(dg.t(), layer_input(l)), torch.matmul(dg.t(), yprev), dB, dB]
+            if direct:
                 for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], g4):
-                    if p_.requires_grad:
-                        overlap._accumulate(p_, g_)
+                    deliver(p_, g_, hl)
                 g4 = [None] * 4
+            else:
+                g4 = [_unperm_rows(g_, hl) for g_ in g4]
             per_layer[l] = g4
         grads = [g for g4 in per_layer for g in g4]
         dX = torch.matmul(dG[0].reshape(T1 * B, 4 * H), Wp[0]).view(T1, B, -1) if need_dx else None
