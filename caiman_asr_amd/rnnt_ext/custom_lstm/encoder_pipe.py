@@ -65,6 +65,13 @@ def _schedule(nA, nB, La, Lb, f, nP=0, Lp=0):
     return [sorted(ticks[t]) for t in sorted(ticks)]
 
 
+def _perm_cast(w, H, dt):
+    """rows [gate][unit] -> [unit][gate] and cast, in one copy kernel (stack._perm_rows + .to)."""
+    out = torch.empty(w.shape, dtype=dt, device=w.device)
+    out.view(H, 4, *w.shape[1:]).copy_(w.view(4, H, *w.shape[1:]).transpose(0, 1))
+    return out
+
+
 def _stacked(src, t0, n, f, B, H):
     """rows of StackTime for post steps [t0, t0+n): src [T1p, B, H] -> [n*B, f*H]."""
     return src[f * t0:f * (t0 + n)].view(n, f, B, H).transpose(1, 2).reshape(n * B, f * H)
@@ -93,13 +100,14 @@ class EncoderPipeFunction(torch.autograd.Function):
         Hp = Rs[Le].shape[1] if Lp else 0
         Hl = [H] * Le + [Hp] * Lp
         Tl = [T1] * La + [T2] * Lb + [Tp] * Lp
-        g0 = torch.addmm(_perm_rows(bWs[0] + bRs[0], H), x.flatten(0, 1), _perm_rows(Ws[0], H).t())
-        dt = g0.dtype
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         tag = _lib.dtype_tag(dt)
+        Rp = [R.to(dt).contiguous() for R in Rs]
+        Wp = [_perm_cast(Ws[l], Hl[l], dt) for l in range(L)]
+        bias = [_perm_cast(bWs[l] + bRs[l], Hl[l], dt) for l in range(L)]
         Ga = torch.empty((La, T1, B, 4 * H), dtype=dt, device=dev)
         Gb = torch.empty((Lb, T2, B, 4 * H), dtype=dt, device=dev)
-        Ga[0].copy_(g0.view(T1, B, 4 * H))
-        del g0
+        torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0].t(), out=Ga[0].view(T1 * B, 4 * H))
         # pre outputs carry f-1 zero frames at the end so that the last stacked frame is zero padded (StackTime)
         Ya = torch.zeros((La, T1p + 1, B, H), dtype=dt, device=dev) if T1p != T1 else torch.empty((La, T1 + 1, B, H), dtype=dt, device=dev)
         Ca = torch.empty((La, T1 + 1, B, H), dtype=dt, device=dev)
@@ -119,14 +127,10 @@ class EncoderPipeFunction(torch.autograd.Function):
             Cp = torch.empty((Lp, Tp + 1, B, Hp), dtype=dt, device=dev)
             Yp[:, 0].copy_(h0p)
             Cp[:, 0].copy_(c0p)
-            Gp[0].copy_(torch.addmm(_perm_rows(bWs[Le] + bRs[Le], Hp), xp.flatten(0, 1), _perm_rows(Ws[Le], Hp).t())
-                        .view(Tp, B, 4 * Hp))
+            torch.addmm(bias[Le], xp.flatten(0, 1).to(dt), Wp[Le].t(), out=Gp[0].view(Tp * B, 4 * Hp))
             G += [Gp[p] for p in range(Lp)]
             Y += [Yp[p] for p in range(Lp)]
             C += [Cp[p] for p in range(Lp)]
-        Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [_perm_rows(Ws[l], Hl[l]).to(dt) for l in range(L)]
-        bias = [_perm_rows(bWs[l] + bRs[l], Hl[l]).to(dt) for l in range(L)]
         drop_e = float(p_drop) if (training and p_drop > 0.0) else 0.0
         drop_p = float(p_drop_pred) if (training and p_drop_pred > 0.0 and Lp > 1) else 0.0
         pl = [drop_e] * Le + [drop_p] * Lp                    # dropout applied to the OUTPUT of layer l when it feeds a layer
