@@ -46,6 +46,13 @@ def _perm_rows(w, H):
     return w.reshape(4, H, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
 
 
+def _perm_cast(w, H, dt):
+    """_perm_rows and a cast in one copy kernel."""
+    out = torch.empty(w.shape, dtype=dt, device=w.device)
+    out.view(H, 4, *w.shape[1:]).copy_(w.view(4, H, *w.shape[1:]).transpose(0, 1))
+    return out
+
+
 def _unperm_rows(w, H):
     """inverse of _perm_rows."""
     return w.reshape(H, 4, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
@@ -93,19 +100,17 @@ class StackFunction(torch.autograd.Function):
         H = Rs[0].shape[1]
         # the pipeline keeps gates / dG unit-major ([.., H, 4]): permute the ROWS of W_ih and of the biases once
         # per call (R keeps its layout: the tiling kernels absorb the permutation)
-        g0 = torch.addmm(_perm_rows(bWs[0] + bRs[0], H), x.flatten(0, 1), _perm_rows(Ws[0], H).t())
-        dt = g0.dtype
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         tag = _lib.dtype_tag(dt)
+        Rp = [R.to(dt).contiguous() for R in Rs]
+        Wp = [_perm_cast(W, H, dt) for W in Ws]
+        bias = [_perm_cast(bWs[l] + bRs[l], H, dt) for l in range(L)]
         G = torch.empty((L, T, B, 4 * H), dtype=dt, device=dev)
-        G[0].copy_(g0.view(T, B, 4 * H))
-        del g0
+        torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0].t(), out=G[0].view(T * B, 4 * H))
         Y = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
         Cs = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
         Y[:, 0].copy_(h0)
         Cs[:, 0].copy_(c0)
-        Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [_perm_rows(W, H).to(dt) for W in Ws]
-        bias = [_perm_rows(bWs[l] + bRs[l], H).to(dt) for l in range(L)]
         drop = float(p_drop) if (training and p_drop > 0.0 and L > 1) else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop > 0.0 else 0
         YM = torch.empty((L - 1, T, B, H), dtype=dt, device=dev) if drop > 0.0 else None  # masked outputs
