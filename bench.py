@@ -331,7 +331,7 @@ def main():
                 try:   # the committed rocprofv3 --kernel-trace --stats summary of this command
                     import csv
 
-                    with open(os.path.join(ROOT, "profiles", "r01_bench_v11_kernel_stats.csv")) as f:
+                    with open(os.path.join(ROOT, "profiles", "r01_bench_v12_kernel_stats.csv")) as f:
                         for row in csv.DictReader(f):
                             if "lstm_bwd_step_mfma" in row["Name"] and "Li8E" in row["Name"]:
                                 out["roofline"]["rocprof_kernel_avg_us"] = float(row["AverageNs"]) / 1e3
