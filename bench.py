@@ -252,7 +252,7 @@ def main():
     barrier()
     if not args.no_kernel_timing:
         _lib.timing.enabled = True
-        _lib.timing.sample_every = {"lstm_fwd": 8, "lstm_bwd": 8}   # see _lib._Timing: every bracket would cost 13 %
+        _lib.timing.sample_every = {"lstm_fwd": 16, "lstm_bwd": 16}   # see _lib._Timing: every bracket would cost 13 %
         _lib.timing.reset()
     audio_s, cells = 0.0, 0
     in_flight = []   # the host may run at most two steps ahead of the device (a real loop reads the loss now and then);
