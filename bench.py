@@ -160,6 +160,7 @@ def main():
         args.no_cpu_baseline = True  # the CPU sample is defined on the base config
     model = RNNT(n_classes=N_CLASSES, **rnnt_cfg).to(dev)
     model.train()
+    model.joint_fc_nt_backward = os.environ.get("CAIMAN_JOINT_NT", "1") != "0"
     model.encoder_pipe = args.encoder_pipe >= 1
     model.pred_in_encoder_pipe = args.encoder_pipe >= 2
     model.overlap_weight_grads = args.overlap and not args.no_overlap

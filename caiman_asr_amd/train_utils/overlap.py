@@ -117,3 +117,35 @@ def linear_overlapped(x, weight, bias):
     """F.linear whose weight / bias gradients are produced on the side stream and added to `.grad` directly
     (autograd sees no gradient for them): call `wait_all()` before using the gradients."""
     return _LinearOverlapped.apply(x, weight, bias)
+
+
+class _LinearTransposedBackward(torch.autograd.Function):
+    """F.linear whose input gradient is computed against a [K, N] copy of the weight.  For the joint projection
+    (rows x 768 x 8704, bf16) the library's `dY · Wᵀᵀ` (NT) kernel runs at 1.36 PF/s where the usual `dY · W` (NN)
+    reaches 1.22 (tools/gemm_layout_bench.py); the 13 MB transposed copy is noise next to the 4 TFLOP GEMM."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.to(dy2.dtype).t().contiguous()           # [K, N]
+            dx = torch.mm(dy2, wt.t()).view(*dy.shape[:-1], weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(dy2.t(), x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0).to(weight.dtype)
+        return dx, dw, db
+
+
+def linear_transposed_backward(x, weight, bias):
+    return _LinearTransposedBackward.apply(x, weight, bias)
