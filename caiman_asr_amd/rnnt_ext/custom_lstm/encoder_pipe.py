@@ -72,6 +72,16 @@ def _perm_cast(w, H, dt):
     return out
 
 
+def _perm_cast_t(w, H, dt):
+    """[4H, K] with rows [gate][unit] -> [K, 4H] with columns [unit][gate], cast: the layout both directions want
+    (forward x · Wt is the library's NN kernel, backward dG · Wtᵀ its NT kernel: 41 vs 69 us for the five post layers
+    of a tick, tools/lstm_gemm_layout_bench.py)."""
+    K = w.shape[1]
+    out = torch.empty((K, w.shape[0]), dtype=dt, device=w.device)
+    out.view(K, H, 4).copy_(w.view(4, H, K).permute(2, 1, 0))
+    return out
+
+
 def _stacked(src, t0, n, f, B, H):
     """rows of StackTime for post steps [t0, t0+n): src [T1p, B, H] -> [n*B, f*H]."""
     return src[f * t0:f * (t0 + n)].view(n, f, B, H).transpose(1, 2).reshape(n * B, f * H)
@@ -103,11 +113,11 @@ class EncoderPipeFunction(torch.autograd.Function):
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         tag = _lib.dtype_tag(dt)
         Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [_perm_cast(Ws[l], Hl[l], dt) for l in range(L)]
+        Wp = [_perm_cast_t(Ws[l], Hl[l], dt) for l in range(L)]   # [K, 4H]
         bias = [_perm_cast(bWs[l] + bRs[l], Hl[l], dt) for l in range(L)]
         Ga = torch.empty((La, T1, B, 4 * H), dtype=dt, device=dev)
         Gb = torch.empty((Lb, T2, B, 4 * H), dtype=dt, device=dev)
-        torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0].t(), out=Ga[0].view(T1 * B, 4 * H))
+        torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=Ga[0].view(T1 * B, 4 * H))
         # pre outputs carry f-1 zero frames at the end so that the last stacked frame is zero padded (StackTime)
         Ya = torch.zeros((La, T1p + 1, B, H), dtype=dt, device=dev) if T1p != T1 else torch.empty((La, T1 + 1, B, H), dtype=dt, device=dev)
         Ca = torch.empty((La, T1 + 1, B, H), dtype=dt, device=dev)
@@ -127,7 +137,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             Cp = torch.empty((Lp, Tp + 1, B, Hp), dtype=dt, device=dev)
             Yp[:, 0].copy_(h0p)
             Cp[:, 0].copy_(c0p)
-            torch.addmm(bias[Le], xp.flatten(0, 1).to(dt), Wp[Le].t(), out=Gp[0].view(Tp * B, 4 * Hp))
+            torch.addmm(bias[Le], xp.flatten(0, 1).to(dt), Wp[Le], out=Gp[0].view(Tp * B, 4 * Hp))
             G += [Gp[p] for p in range(Lp)]
             Y += [Yp[p] for p in range(Lp)]
             C += [Cp[p] for p in range(Lp)]
@@ -163,7 +173,7 @@ class EncoderPipeFunction(torch.autograd.Function):
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), False) if h else 0 for h in Hl]
-        Wt_post = torch.stack([Wp[l].t() for l in range(La + 1, Le)]) if (BMM and Lb > 2) else None      # [Lb-1, H, 4H]
+        Wt_post = torch.stack([Wp[l] for l in range(La + 1, Le)]) if (BMM and Lb > 2) else None      # [Lb-1, H, 4H]
         b_post = torch.stack([bias[l] for l in range(La + 1, Le)]).unsqueeze(1) if Wt_post is not None else None
         for tick in _schedule(nA, nB, La, Lb, f, nP, Lp):
             slots, nbytes = [], 0
@@ -190,7 +200,7 @@ class EncoderPipeFunction(torch.autograd.Function):
                         src = _stacked(src_all, t0, n, f, B, H)
                     else:
                         src = (YM[l - 1][t0:t0 + n] if pl[l - 1] > 0.0 else Y[l - 1][1 + t0:1 + t0 + n]).reshape(n * B, hl)
-                    torch.addmm(bias[l], src, Wp[l].t(), out=G[l][t0:t0 + n].view(n * B, 4 * hl))
+                    torch.addmm(bias[l], src, Wp[l], out=G[l][t0:t0 + n].view(n * B, 4 * hl))
                 masked = pl[l] > 0.0 and l not in top
                 slots.append(_lib.FwdSlot(wt[l].data_ptr(), G[l][t0].data_ptr(), C[l][t0].data_ptr(), Y[l][t0].data_ptr(),
                                           ring[l].data_ptr(), t0 & 1, n, YM[l][t0].data_ptr() if masked else None,
@@ -276,7 +286,7 @@ class EncoderPipeFunction(torch.autograd.Function):
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), True) if h else 0 for h in Hl]
         boundary_done = set()   # post chunks whose input gradient has been un-stacked into delta[La-1]
-        W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]) if (BMM and Lb > 2) else None      # [Lb-1, 4H, H]
+        W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]).transpose(1, 2) if (BMM and Lb > 2) else None   # views [Lb-1, 4H, H]
         for tick in reversed(_schedule(nA, nB, La, Lb, f, nP, Lp)):
             slots, nbytes = [], 0
             batched = set()
@@ -297,10 +307,10 @@ class EncoderPipeFunction(torch.autograd.Function):
                     if j not in boundary_done:
                         boundary_done.add(j)
                         p0, pn = j * CHb, min(CHb, T2 - j * CHb)
-                        dx2 = torch.matmul(dG[La][p0:p0 + pn].view(pn * B, 4 * H), Wp[La])       # [pn*B, f*H]
+                        dx2 = torch.matmul(dG[La][p0:p0 + pn].view(pn * B, 4 * H), Wp[La].t())   # [pn*B, f*H]
                         delta[l][f * p0:f * (p0 + pn)].view(pn, f, B, H).copy_(dx2.view(pn, B, f, H).transpose(1, 2))
                 elif l not in top and l not in batched:   # dX = dG_{l+1} @ W_{l+1} of the same chunk
-                    torch.matmul(dG[l + 1][t0:t0 + n].view(n * B, 4 * hl), Wp[l + 1], out=delta[l][t0:t0 + n].view(n * B, hl))
+                    torch.matmul(dG[l + 1][t0:t0 + n].view(n * B, 4 * hl), Wp[l + 1].t(), out=delta[l][t0:t0 + n].view(n * B, hl))
                 d = delta[l]
                 p_slot = pl[l] if l not in top else 0.0
                 slots.append(_lib.BwdSlot(wt[l].data_ptr(), G[l][thi].data_ptr(), C[l][thi].data_ptr(), d[thi].data_ptr(),
@@ -382,8 +392,8 @@ class EncoderPipeFunction(torch.autograd.Function):
                 g4 = [_unperm_rows(g_, hl) for g_ in g4]
             per_layer[l] = g4
         grads = [g for g4 in per_layer for g in g4]
-        dX = torch.matmul(dG[0].reshape(T1 * B, 4 * H), Wp[0]).view(T1, B, -1) if need_dx else None
-        dXp = torch.matmul(dG[Le].reshape(Tp * B, 4 * Hp), Wp[Le]).view(Tp, B, -1) if (Lp and need_dxp) else None
+        dX = torch.matmul(dG[0].reshape(T1 * B, 4 * H), Wp[0].t()).view(T1, B, -1) if need_dx else None
+        dXp = torch.matmul(dG[Le].reshape(Tp * B, 4 * Hp), Wp[Le].t()).view(Tp, B, -1) if (Lp and need_dxp) else None
         return (dX, None, None, None, None, None, None, None, None, None, None, dXp, None, None, None, *grads)
 
 

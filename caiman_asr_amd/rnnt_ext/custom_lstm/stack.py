@@ -46,6 +46,14 @@ def _perm_rows(w, H):
     return w.reshape(4, H, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
 
 
+def _perm_cast_t(w, H, dt):
+    """[4H, K] rows [gate][unit] -> [K, 4H] columns [unit][gate], cast, in one copy kernel."""
+    K = w.shape[1]
+    out = torch.empty((K, w.shape[0]), dtype=dt, device=w.device)
+    out.view(K, H, 4).copy_(w.view(4, H, K).permute(2, 1, 0))
+    return out
+
+
 def _perm_cast(w, H, dt):
     """_perm_rows and a cast in one copy kernel."""
     out = torch.empty(w.shape, dtype=dt, device=w.device)
@@ -103,10 +111,10 @@ class StackFunction(torch.autograd.Function):
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         tag = _lib.dtype_tag(dt)
         Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [_perm_cast(W, H, dt) for W in Ws]
+        Wp = [_perm_cast_t(W, H, dt) for W in Ws]    # [K, 4H]: NN forward, NT backward (tools/lstm_gemm_layout_bench.py)
         bias = [_perm_cast(bWs[l] + bRs[l], H, dt) for l in range(L)]
         G = torch.empty((L, T, B, 4 * H), dtype=dt, device=dev)
-        torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0].t(), out=G[0].view(T * B, 4 * H))
+        torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=G[0].view(T * B, 4 * H))
         Y = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
         Cs = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
         Y[:, 0].copy_(h0)
@@ -134,7 +142,7 @@ class StackFunction(torch.autograd.Function):
                 t0, n = k * CH, min(CH, T - k * CH)
                 if l >= 1:  # input GEMM of this layer's chunk on what layer l-1 produced last tick
                     src = YM[l - 1, t0:t0 + n] if drop > 0.0 else Y[l - 1, 1 + t0:1 + t0 + n]
-                    torch.addmm(bias[l], src.reshape(n * B, H), Wp[l].t(), out=G[l, t0:t0 + n].view(n * B, 4 * H))
+                    torch.addmm(bias[l], src.reshape(n * B, H), Wp[l], out=G[l, t0:t0 + n].view(n * B, 4 * H))
                 masked = drop > 0.0 and l < L - 1
                 slots.append(_lib.FwdSlot(wt[l].data_ptr(), G[l, t0].data_ptr(), Cs[l, t0].data_ptr(),
                                           Y[l, t0].data_ptr(), ring[l].data_ptr(), t0 & 1, n,
@@ -210,7 +218,7 @@ class StackFunction(torch.autograd.Function):
                 p_slot = 0.0
                 if l < L - 1:  # gradient from the layer above for this chunk: dX = dG_{l+1} @ W_{l+1}
                     out = delta_low[l, t0:t0 + n].view(n * B, H)
-                    torch.matmul(dG[l + 1, t0:t0 + n].view(n * B, 4 * H), Wp[l + 1], out=out)
+                    torch.matmul(dG[l + 1, t0:t0 + n].view(n * B, 4 * H), Wp[l + 1].t(), out=out)
                     if drop > 0.0:
                         if fused_mask:
                             p_slot = drop
@@ -244,7 +252,7 @@ class StackFunction(torch.autograd.Function):
             return [_unperm_rows(torch.matmul(dg.t(), xin), H),
                     _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
 
-        dX = torch.matmul(dG[0].view(T * B, 4 * H), Wp[0]).view(T, B, -1) if need_dx else None
+        dX = torch.matmul(dG[0].view(T * B, 4 * H), Wp[0].t()).view(T, B, -1) if need_dx else None
         if OVERLAP_WEIGHT_GRADS:
             from caiman_asr_amd.train_utils import overlap
 
