@@ -19,6 +19,8 @@
 //   "GEMV / M<=16" row); see the MFMA section below for the layout and the measurements.
 // A generic scalar kernel covers f32 / f64 and sizes the MFMA tiles do not divide.
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -507,6 +509,219 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int st
   dC[(int64_t)be * H + ne] = dc * gf;
 }
 
+// ===========================================================================
+// Weight-resident chunk kernels.
+//
+// The step kernels above re-read every slot's recurrent matrix (8 MB at H = 1024) on every launch: with the eight
+// encoder layers of a pipeline tick in flight that is 64 MB per timestep, and the launch runs at the rate the
+// Infinity Cache delivers it (12 us; profiles/r01_pmc_traffic.json).  Here ONE launch covers all timesteps of the
+// tick.  A slot is served by H/32 workgroups of 4 waves; a wave owns 8 hidden units (32 gate rows) and keeps their
+// rows of R, all K, in registers for the whole launch (2 x H/32 MFMA A-fragments = 256 VGPRs at H = 1024), so a
+// workgroup needs a CU to itself and the grid (slots x H/32 <= number of CUs) is co-resident by construction.
+// Per timestep the workgroups of one slot exchange h through the y row they write anyway:
+//   write-through (sc1) 8-byte stores -> every wave drains -> barrier -> one lane adds to the slot's counter;
+//   one lane polls that counter relaxed, ONE agent acquire, barrier, then plain 16-byte loads of the whole row
+//   into LDS (MI355X_MICROARCH.md "inter-workgroup visibility": producer R1 / consumer recipe).
+// Rows are written once and never overwritten inside a launch, so there is no second (read-done) barrier.
+// The MFMA is transposed with respect to the step kernel: A = 16 gate rows of R ordered [unit][gate], B = h^T, so
+// a lane ends up with the four gates of ONE (unit, batch row) in its four accumulator registers and the cell
+// update needs no cross-lane traffic; c stays in a register between steps (rounded to the storage type each step,
+// as the step kernel's round trip through memory does).
+// Every spin is bounded by a wall-clock limit; a timeout raises `fail` (host-visible) and the workgroup leaves.
+// ===========================================================================
+constexpr int kResTimeoutTicks = 5000000;   // wall_clock64 runs at 100 MHz: 50 ms
+constexpr int kResCounterStride = 32;       // one 128-byte line per slot counter
+
+__device__ __forceinline__ bool res_wait(unsigned* cnt, unsigned target, unsigned* fail_dev, unsigned* fail_host) {
+  const long long t0 = wall_clock64();
+  unsigned spins = 0;
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) == 0u) {
+      if (__hip_atomic_load(fail_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if (wall_clock64() - t0 > kResTimeoutTicks) {
+        __hip_atomic_store(fail_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(fail_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+template <typename T, bool HARD, int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32, LDH = H + 8;   // LDS row pitch: +16 bytes keeps the 16 lanes of a b128 read on distinct banks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* hs = reinterpret_cast<T*>(smem);                       // [32][LDH]
+  T* tr = hs + 32 * LDH;                                    // [4 waves][2: h, c][32 rows][8 units]
+  int* flag = reinterpret_cast<int*>(tr + 4 * 2 * 32 * 8);  // abort broadcast
+
+  const int slot = blockIdx.y, j = blockIdx.x;
+  const int nsteps = w.nsteps[slot];
+  if (nsteps <= 0) return;
+  const int nwg = gridDim.x;
+  unsigned* cnt = sync + slot * kResCounterStride;
+  unsigned* fail_dev = sync + kMaxSlots * kResCounterStride;
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int u0 = j * 32 + wave * 8;   // first hidden unit of this wave
+
+  // resident A fragments: row m of a 16-row tile = (unit m>>2, gate m&3); tile_R_fwd_kernel stores n = gate*4 + unit
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rtile[slot];
+    const int n = (r & 3) * 4 + (r >> 2);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)j * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) wreg[rt][s] = *reinterpret_cast<const frag*>(Rt + ((blk * NKS + s) * 16 + n) * 32 + 8 * kq);
+    }
+  }
+  // this lane's cells: unit u0 + rt*4 + kq, batch row ct*16 + r
+  float creg[2][2];
+  g4 gcur[2][2], gnext[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gcur[i >> 1][i & 1][q] = static_cast<T>(0.f);
+  {
+    const T* c0 = w.c[slot];
+    const T* g = w.g[slot];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = ct * 16 + r, u = u0 + rt * 4 + kq;
+        creg[rt][ct] = b < B ? static_cast<float>(c0[(int64_t)b * H + u]) : 0.f;
+        if (b < B) gcur[rt][ct] = *reinterpret_cast<const g4*>(g + ((int64_t)b * H + u) * 4);
+        gnext[rt][ct] = gcur[rt][ct];
+      }
+  }
+  if (tid == 0) *flag = 0;
+  T* trh = tr + wave * (2 * 32 * 8);
+  T* trc = trh + 32 * 8;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+
+  for (int s = 0; s < nsteps; ++s) {
+    T* g = w.g[slot] + go * s;
+    if (s + 1 < nsteps) {   // next step's pre-activations: independent of h, in flight across the wait
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int b = ct * 16 + r, u = u0 + rt * 4 + kq;
+          if (b < B) gnext[rt][ct] = *reinterpret_cast<const g4*>(g + go + ((int64_t)b * H + u) * 4);
+        }
+    }
+    if (s > 0 && tid == 0) {
+      if (!res_wait(cnt, (unsigned)nwg * (unsigned)s, fail_dev, fail_host)) *flag = 1;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (*flag) break;
+    // h of this step: row s of y, [B][H] row-major -> LDS (rows >= B are zero)
+    {
+      const T* hrow = w.y[slot] + so * s;
+      constexpr int PER = 32 * H / 8 / 256;   // 16-byte pieces per thread
+      frag v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+        if (b < B) v[i] = *reinterpret_cast<const frag*>(hrow + (int64_t)b * H + k8 * 8);
+        else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[i][q] = static_cast<T>(0.f);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+        *reinterpret_cast<frag*>(hs + b * LDH + k8 * 8) = v[i];
+      }
+    }
+    __syncthreads();
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const frag b0 = *reinterpret_cast<const frag*>(hs + r * LDH + ks * 32 + kq * 8);
+      const frag b1 = *reinterpret_cast<const frag*>(hs + (16 + r) * LDH + ks * 32 + kq * 8);
+      acc[0][0] = mfma16(wreg[0][ks], b0, acc[0][0]);
+      acc[0][1] = mfma16(wreg[0][ks], b1, acc[0][1]);
+      acc[1][0] = mfma16(wreg[1][ks], b0, acc[1][0]);
+      acc[1][1] = mfma16(wreg[1][ks], b1, acc[1][1]);
+    }
+    // cell update, lane-local: acc register q = gate q of (unit kq of the row tile, batch row r of the column tile)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = ct * 16 + r, ul = rt * 4 + kq;
+        const float pi = static_cast<float>(gcur[rt][ct][0]) + acc[rt][ct][0];
+        const float pf = static_cast<float>(gcur[rt][ct][1]) + acc[rt][ct][1];
+        const float pg = static_cast<float>(gcur[rt][ct][2]) + acc[rt][ct][2];
+        const float po = static_cast<float>(gcur[rt][ct][3]) + acc[rt][ct][3];
+        const float ig = Act<float, HARD>::sigm(pi), fg = Act<float, HARD>::sigm(pf);
+        const float gg = Act<float, HARD>::tanhv(pg), og = Act<float, HARD>::sigm(po);
+        const float c = ig * gg + fg * creg[rt][ct];
+        const T cv = static_cast<T>(c);
+        const T yv = static_cast<T>(og * Act<float, HARD>::tanhv(c));
+        creg[rt][ct] = static_cast<float>(cv);
+        trh[b * 8 + ul] = yv;
+        trc[b * 8 + ul] = cv;
+        if (b < B) {
+          g4 v;
+          v[0] = static_cast<T>(ig); v[1] = static_cast<T>(fg); v[2] = static_cast<T>(gg); v[3] = static_cast<T>(og);
+          *reinterpret_cast<g4*>(g + ((int64_t)b * H + u0 + ul) * 4) = v;
+        }
+        gcur[rt][ct] = gnext[rt][ct];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      // lane -> (batch row lane>>1, 4 units): one 8-byte piece of the h row (write-through) and of the c row
+      const int b = lane >> 1, half = lane & 1;
+      if (b < B) {
+        const g4 hv = *reinterpret_cast<const g4*>(trh + b * 8 + half * 4);
+        const g4 cv = *reinterpret_cast<const g4*>(trc + b * 8 + half * 4);
+        const int64_t e = (int64_t)b * H + u0 + half * 4;
+        unsigned long long hbits;
+        __builtin_memcpy(&hbits, &hv, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(w.y[slot] + so * (s + 1) + e), hbits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
+        if (w.ymask[slot]) {
+          g4 mv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
+            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
+          }
+          *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
+        }
+        if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
+          const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+          T* h_out = w.hring[slot] + ((w.parity[slot] + nsteps) & 1) * hsz;
+          *reinterpret_cast<g4*>(h_out + tiled_index(b, u0 + half * 4, NKS)) = hv;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <typename T>
 constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value;
 
@@ -556,6 +771,88 @@ int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t 
 #undef CAIMAN_BWD
   }
   return check_launch("lstm backward wave");
+}
+
+// ---- resident launch state: per-device pool of zeroed counter blocks + a host-visible failure word ----
+constexpr int kResPool = 32;
+constexpr size_t kResSyncBytes = (size_t)(kMaxSlots + 1) * kResCounterStride * sizeof(unsigned);
+struct ResState {
+  unsigned* sync[kResPool] = {};
+  unsigned* fail_host = nullptr;
+  int next = 0;
+  int cus = 0;
+  bool ok = false;
+};
+std::mutex g_res_mu;
+ResState g_res[16];
+std::atomic<int> g_res_mode{0};
+
+ResState* res_state() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  ResState& st = g_res[dev];
+  if (!st.ok) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+    st.cus = prop.multiProcessorCount;
+    if (hipHostMalloc(reinterpret_cast<void**>(&st.fail_host), 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+    *st.fail_host = 0;
+    for (int i = 0; i < kResPool; ++i)
+      if (hipMalloc(reinterpret_cast<void**>(&st.sync[i]), kResSyncBytes) != hipSuccess) return nullptr;
+    st.ok = true;
+  }
+  return &st;
+}
+
+template <typename T>
+inline size_t res_fwd_lds(int H) { return (size_t)(32 * (H + 8) + 4 * 2 * 32 * 8) * sizeof(T) + 16; }
+
+// true when the launch was taken by the resident kernel
+template <typename T, bool HARD>
+bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!g_res_mode.load(std::memory_order_relaxed) || B > 32 || n_launches < 2) return false;
+  for (int i = 0; i < n_slots; ++i)
+    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;   // one width per launch
+  const int nks = (int)(H / 32);
+  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
+  ResState* st = res_state();
+  if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  unsigned* sync;
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    sync = st->sync[st->next];
+    st->next = (st->next + 1) % kResPool;
+  }
+  if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const size_t lds = res_fwd_lds<T>((int)H);
+#define CAIMAN_RES(NKV)                                                                                              \
+  do {                                                                                                               \
+    auto kern = lstm_fwd_resident<T, HARD, NKV>;                                                                     \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)res_fwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
+        *err = check_launch("lstm resident attribute");                                                              \
+        return true;                                                                                                 \
+      }                                                                                                              \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
+  } while (0)
+  switch (nks) {
+    case 2: CAIMAN_RES(2); break;
+    case 4: CAIMAN_RES(4); break;
+    case 8: CAIMAN_RES(8); break;
+    case 16: CAIMAN_RES(16); break;
+    case 24: CAIMAN_RES(24); break;
+    default: CAIMAN_RES(32); break;
+  }
+#undef CAIMAN_RES
+  *err = check_launch("lstm resident forward");
+  return true;
 }
 
 template <typename T>
@@ -664,6 +961,23 @@ extern "C" int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uin
   return check_launch("caiman_lstm_dropout_mask");
 }
 
+// Weight-resident chunk kernels (above): 0 = per-timestep launches only, 1 = one launch per call where the shapes
+// allow it (interleaved gates, B <= 32, one hidden size per call, slots x H/32 workgroups <= CUs).  Returns the
+// previous mode.
+extern "C" int caiman_lstm_resident_mode(int mode) {
+  return caiman::g_res_mode.exchange(mode ? 1 : 0);
+}
+
+// Number of resident-kernel workgroups that gave up waiting for their peers since the library was loaded (0 in a
+// healthy run; results of such a launch are invalid).  Reads host memory: no device synchronisation.
+extern "C" int caiman_lstm_resident_failures(void) {
+  using namespace caiman;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  return g_res[dev].ok ? (int)*reinterpret_cast<volatile unsigned*>(g_res[dev].fail_host) : 0;
+}
+
 // ---- multi-layer ("wave") interface -----------------------------------------------------------------
 extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
                                    int64_t B, int64_t H, int dtype, int backward, int gate_layout,
@@ -707,6 +1021,12 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
       CAIMAN_CHECK(slots[i].drop_p >= 0.f && slots[i].drop_p < 1.f, "lstm_wave_fwd: dropout p must be in [0,1)");
     }
     w.seed = seed;
+    if (gate_layout) {
+      int err = CAIMAN_OK;
+      if (hard ? try_fwd_resident<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_fwd_resident<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
+    }
     if (gate_layout)
       return hard ? launch_fwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
                   : launch_fwd_waves<T, false, true>(w, n_slots, n_launches, B, H, s);

@@ -177,6 +177,15 @@ int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n
                          uint64_t seed, caiman_stream_t stream);
 int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base, float p, int dtype,
                              caiman_stream_t stream);
+/* Weight-resident variant of the wave calls (same slots, same results up to fp32 summation order): with mode 1 a
+ * wave call whose shapes allow it (interleaved gates, B <= 32, one hidden size, n_slots * H/32 workgroups not more
+ * than the device has CUs) runs ALL its timesteps in one launch, each workgroup keeping its rows of R in registers
+ * and the workgroups of a slot meeting at a device counter once per timestep; other calls keep the per-timestep
+ * launches.  Replaces the same time loop (training/lib/csrc/lstm.cu:214-346).  caiman_lstm_resident_mode returns the
+ * previous mode; caiman_lstm_resident_failures counts workgroups that timed out waiting (0 in a healthy process; a
+ * non-zero value invalidates the results of that launch) and does not synchronise the device. */
+int caiman_lstm_resident_mode(int mode);
+int caiman_lstm_resident_failures(void);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
