@@ -549,6 +549,26 @@ __device__ __forceinline__ bool res_wait(unsigned* cnt, unsigned target, unsigne
   return true;
 }
 
+// 16-byte write-through (sc1) buffer accesses for rows that workgroups hand to each other inside a launch
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+template <typename T>
+__device__ __forceinline__ typename frag8<T>::type res_load16(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);   // aux 16 = sc1
+  typename frag8<T>::type f;
+  __builtin_memcpy(&f, &v, 16);
+  return f;
+}
+template <typename V>
+__device__ __forceinline__ void res_store16(const V& val, __amdgpu_buffer_rsrc_t rs, int byte_off) {
+  static_assert(sizeof(V) == 16, "16-byte store");
+  u32x4 v;
+  __builtin_memcpy(&v, &val, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);
+}
+
 template <typename T, bool HARD, int NKS>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
   using frag = typename frag8<T>::type;
@@ -621,20 +641,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
     }
     if (s > 0 && tid == 0) {
       if (!res_wait(cnt, (unsigned)nwg * (unsigned)s, fail_dev, fail_host)) *flag = 1;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __syncthreads();
     if (*flag) break;
-    // h of this step: row s of y, [B][H] row-major -> LDS (rows >= B are zero)
+    // h of this step: row s of y, [B][H] row-major -> LDS (rows >= B are zero).  Every load of handed-off bytes is
+    // an sc1 load to registers, which stands in for the agent acquire (visibility table, first row).
     {
-      const T* hrow = w.y[slot] + so * s;
-      constexpr int PER = 32 * H / 8 / 256;   // 16-byte pieces per thread
+      const __amdgpu_buffer_rsrc_t rs = res_rsrc(w.y[slot] + so * s);
+      constexpr int PER = (32 * H / 8 + 255) / 256;   // 16-byte pieces per thread
       frag v[PER];
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
-        if (b < B) v[i] = *reinterpret_cast<const frag*>(hrow + (int64_t)b * H + k8 * 8);
+        if (b < B) v[i] = res_load16<T>(rs, (b * H + k8 * 8) * (int)sizeof(T));
         else {
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[i][q] = static_cast<T>(0.f);
@@ -643,7 +663,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
-        *reinterpret_cast<frag*>(hs + b * LDH + k8 * 8) = v[i];
+        if (b < 32) *reinterpret_cast<frag*>(hs + b * LDH + k8 * 8) = v[i];
       }
     }
     __syncthreads();
@@ -717,6 +737,176 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Backward counterpart: dh[t] = delta[t] + dG[t+1]·R with K = 4H.  A workgroup owns 32 hidden units and keeps the
+// matching 32 columns of R (as rows of Rᵀ, all 4H of K: again 256 KB at H = 1024) in registers: wave (rt, kh) holds
+// the 16-unit row tile rt for half of the k-steps.  The operand every workgroup needs is the whole dG row of the
+// step before (32 x 4H, 256 KB): it is streamed through LDS in four H-wide stages, double buffered, each wave
+// multiplying its half of a stage while the next one is in flight; the two K-halves meet in LDS and 256 threads
+// finish 4 units of one batch row each (32-byte dG pieces, written through for the next step's readers).
+// dC stays in registers across the launch.
+template <typename T, bool HARD, int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32, LDH = H + 8, HK = NKS / 2;   // HK: k-steps per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* buf = reinterpret_cast<T*>(smem);                                  // [2][32][LDH]
+  float* red = reinterpret_cast<float*>(buf + 2 * 32 * LDH);            // [kh 2][rt 2][ct 2][16 units][17]
+  int* flag = reinterpret_cast<int*>(red + 8 * 16 * 17);
+
+  const int slot = blockIdx.y, j = blockIdx.x;
+  const int nsteps = w.nsteps[slot];
+  if (nsteps <= 0) return;
+  const int nwg = gridDim.x;
+  unsigned* cnt = sync + slot * kResCounterStride;
+  unsigned* fail_dev = sync + kMaxSlots * kResCounterStride;
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int rt = wave & 1, kh = wave >> 1;
+
+  frag wreg[4][HK];
+  {
+    const T* Rt = w.Rttile[slot];
+    const int64_t blk = (int64_t)j * 2 + rt;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < HK; ++i) {
+        const int sidx = q * NKS + kh * HK + i;
+        wreg[q][i] = *reinterpret_cast<const frag*>(Rt + ((blk * (4 * NKS) + sidx) * 16 + r) * 32 + 8 * kq);
+      }
+  }
+  // epilogue role: batch row eb, units u .. u+3
+  const int eb = tid >> 3, ul4 = (tid & 7) * 4, u = j * 32 + ul4;
+  const bool ep = eb < B;
+  const int64_t eoff = (int64_t)eb * H + u;
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ep) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoff);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dcs[q] = v[q];
+  }
+  if (tid == 0) *flag = 0;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+  const int64_t d_st = w.d_st[slot], d_sb = w.d_sb[slot];
+  constexpr int PER = (32 * H / 8 + 255) / 256;
+
+  for (int s = 0; s < nsteps; ++s) {
+    const T* g = w.g[slot] - go * s;
+    const T* c_prev = w.c[slot] - so * s;
+    const T* delta = w.delta[slot] - d_st * s;
+    T* dG = w.dG[slot] - go * s;
+    const bool has_in = s > 0 || w.has_in0[slot];
+    // epilogue inputs: none of them depends on the recurrence, so they travel while the workgroup waits
+    frag gv0, gv1;
+    g4 cpv, ccv, dlv;
+    if (ep) {
+      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4);
+      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4 + 8);
+      cpv = *reinterpret_cast<const g4*>(c_prev + eoff);
+      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoff);
+      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)eb * d_sb + u);
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (has_in) {
+      if (s > 0 && tid == 0) {
+        if (!res_wait(cnt, (unsigned)nwg * (unsigned)s, fail_dev, fail_host)) *flag = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (*flag) break;
+      const __amdgpu_buffer_rsrc_t rs = res_rsrc(dG + go);   // dG of the step before: row t+1, [B][4H]
+      frag v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+        if (b < B) v[i] = res_load16<T>(rs, (b * 4 * H + k8 * 8) * (int)sizeof(T));
+        else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[i][q] = static_cast<T>(0.f);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T* bq = buf + (q & 1) * (32 * LDH);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+          if (b < 32) *reinterpret_cast<frag*>(bq + b * LDH + k8 * 8) = v[i];
+        }
+        if (q < 3) {
+#pragma unroll
+          for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+            if (b < B) v[i] = res_load16<T>(rs, (b * 4 * H + (q + 1) * H + k8 * 8) * (int)sizeof(T));
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < HK; ++i) {
+          const int kk = (kh * HK + i) * 32 + kq * 8;
+          const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDH + kk);
+          const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDH + kk);
+          acc[0] = mfma16(wreg[q][i], b0, acc[0]);
+          acc[1] = mfma16(wreg[q][i], b1, acc[1]);
+        }
+      }
+    }
+    // C layout: column lane&15 = batch row of the column tile, row kq*4 + reg = unit of the row tile
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[(((kh * 2 + rt) * 2 + ct) * 16 + kq * 4 + q) * 17 + r] = acc[ct][q];
+    __syncthreads();
+    if (ep) {
+      const int ert = ul4 >> 4, ect = eb >> 4, ebl = eb & 15, eul = ul4 & 15;
+      g4 vI, vF, vG, vO;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float dy = static_cast<float>(dlv[q]);
+        if (pd > 0.f) {
+          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
+          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
+        }
+        if (has_in)
+          dy += red[(((0 * 2 + ert) * 2 + ect) * 16 + eul + q) * 17 + ebl] + red[(((1 * 2 + ert) * 2 + ect) * 16 + eul + q) * 17 + ebl];
+        const frag& gv = q < 2 ? gv0 : gv1;
+        const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
+        const float gg = static_cast<float>(gv[(q & 1) * 4 + 2]), go_ = static_cast<float>(gv[(q & 1) * 4 + 3]);
+        const float cp = static_cast<float>(cpv[q]), cc = static_cast<float>(ccv[q]);
+        const float ct = Act<float, HARD>::tanhv(cc);
+        const float dc = dy * go_ * Act<float, HARD>::tanh_prime(ct) + dcs[q];
+        vI[q] = static_cast<T>(dc * gg * Act<float, HARD>::sigm_prime(gi));
+        vF[q] = static_cast<T>(dc * cp * Act<float, HARD>::sigm_prime(gf));
+        vG[q] = static_cast<T>(dc * gi * Act<float, HARD>::tanh_prime(gg));
+        vO[q] = static_cast<T>(dy * ct * Act<float, HARD>::sigm_prime(go_));
+        dcs[q] = dc * gf;
+      }
+      frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
+      o0[0] = vI[0]; o0[1] = vF[0]; o0[2] = vG[0]; o0[3] = vO[0]; o0[4] = vI[1]; o0[5] = vF[1]; o0[6] = vG[1]; o0[7] = vO[1];
+      o1[0] = vI[2]; o1[1] = vF[2]; o1[2] = vG[2]; o1[3] = vO[2]; o1[4] = vI[3]; o1[5] = vF[3]; o1[6] = vG[3]; o1[7] = vO[3];
+      const __amdgpu_buffer_rsrc_t ro = res_rsrc(dG);
+      res_store16(o0, ro, (int)(eoff * 4) * (int)sizeof(T));
+      res_store16(o1, ro, (int)(eoff * 4 + 8) * (int)sizeof(T));
+      if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
+        const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+        T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4, 4 * NKS)) = o0;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4 + 8, 4 * NKS)) = o1;
+        f32x4 dv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv[q] = dcs[q];
+        *reinterpret_cast<f32x4*>(w.dC[slot] + eoff) = dv;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -852,6 +1042,60 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   }
 #undef CAIMAN_RES
   *err = check_launch("lstm resident forward");
+  return true;
+}
+
+template <typename T>
+inline size_t res_bwd_lds(int H) { return (size_t)(2 * 32 * (H + 8)) * sizeof(T) + (size_t)8 * 16 * 17 * sizeof(float) + 16; }
+
+template <typename T, bool HARD>
+bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!g_res_mode.load(std::memory_order_relaxed) || B > 32 || n_launches < 2) return false;
+  for (int i = 0; i < n_slots; ++i) {
+    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;
+    // the epilogue moves delta in 8-byte and dC in 16-byte pieces
+    if ((reinterpret_cast<uintptr_t>(w.delta[i]) & 7u) || (w.d_sb[i] & 3) || (w.d_st[i] & 3) ||
+        (reinterpret_cast<uintptr_t>(w.dC[i]) & 15u))
+      return false;
+  }
+  const int nks = (int)(H / 32);
+  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
+  ResState* st = res_state();
+  if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  unsigned* sync;
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    sync = st->sync[st->next];
+    st->next = (st->next + 1) % kResPool;
+  }
+  if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const size_t lds = res_bwd_lds<T>((int)H);
+#define CAIMAN_RES(NKV)                                                                                              \
+  do {                                                                                                               \
+    auto kern = lstm_bwd_resident<T, HARD, NKV>;                                                                     \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)res_bwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
+        *err = check_launch("lstm resident attribute");                                                              \
+        return true;                                                                                                 \
+      }                                                                                                              \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
+  } while (0)
+  switch (nks) {
+    case 2: CAIMAN_RES(2); break;
+    case 4: CAIMAN_RES(4); break;
+    case 8: CAIMAN_RES(8); break;
+    case 16: CAIMAN_RES(16); break;
+    case 24: CAIMAN_RES(24); break;
+    default: CAIMAN_RES(32); break;
+  }
+#undef CAIMAN_RES
+  *err = check_launch("lstm resident backward");
   return true;
 }
 
@@ -1064,6 +1308,12 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
       w.hidden[i] = slots[i].hidden;
     }
     w.seed = seed;
+    if (gate_layout) {
+      int err = CAIMAN_OK;
+      if (hard ? try_bwd_resident<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_bwd_resident<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
+    }
     if (gate_layout)
       return hard ? launch_bwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
                   : launch_bwd_waves<T, false, true>(w, n_slots, n_launches, B, H, s);

@@ -71,6 +71,17 @@ def timing(T, B, I, H, L, reps):
                 m(x, (h0, c0))
             torch.cuda.synchronize()
         out[name + "_ms"] = (time.perf_counter() - t0) * 1e3 / reps
+        xg = x.clone().requires_grad_(True)
+        for i in range(3 + reps):
+            if i == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            m.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y, _, _ = m(xg, (h0, c0))
+            y.float().sum().backward()
+        torch.cuda.synchronize()
+        out[name + "_fwd_bwd_ms"] = (time.perf_counter() - t0) * 1e3 / reps
     lib.caiman_lstm_resident_mode(0)
     out.update({"T": T, "B": B, "H": H, "L": L})
     return out
