@@ -307,34 +307,40 @@ def main():
         if not args.no_kernel_timing:
             summ = _lib.timing_summary()
             out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in summ.items()}
-            # Roofline of the dominant kernel (profiles/: lstm_bwd_step_mfma): one launch = one backward
-            # timestep of every LSTM layer that is active in the layer pipeline (1..6 layers per launch).
-            # HBM-bound by construction: the recurrent weights are re-streamed every step because L2
-            # does not survive a kernel boundary. Algorithmic bytes per layer-step:
-            # rnnt_ext/cuda/lstm.py::_step_bytes; a launch carries the sum over its layers.
+            # Roofline of the dominant hand-written kernel: the backward LSTM recurrence.  With the weight-resident
+            # chunk kernel (csrc/lstm.hip, default) one launch = all timesteps of one pipeline tick for every active
+            # layer (up to 8): each layer reads its recurrent matrix ONCE per launch plus the per-timestep operands
+            # (rnnt_ext/cuda/lstm.py::_step_bytes minus the weights).  With per-timestep launches (mode 0, or shapes
+            # the resident kernel does not take) one launch = one timestep and the weights are re-read every launch.
+            # Either way the kernel is a chain of dependent timesteps: `us_per_timestep` is the figure that moves.
             if "lstm_bwd" in summ:
-                _, ms, launches, nbytes = summ["lstm_bwd"]
+                brackets, ms, launches, nbytes, tsteps = summ["lstm_bwd"]
+                resident = launches < 1.5 * brackets
+                kname = "lstm_bwd_resident" if resident else "lstm_bwd_step_mfma"
                 achieved = nbytes / (ms * 1e-3) / 1e9
                 traffic = None  # PMC counters need their own rocprofv3 passes: read the committed measurement
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                    traffic = pmc["lstm_bwd_step_mfma"]["traffic_bytes_per_launch"]
+                    traffic = pmc[kname]["traffic_bytes_per_launch"]
                 except Exception:
                     pass
-                out["roofline"] = {"kernel": "lstm_bwd_step_mfma (one backward timestep of all pipelined LSTM layers per launch)",
+                out["roofline"] = {"kernel": (kname + (" (all backward timesteps of one pipeline tick, every active LSTM layer, per launch)"
+                                                       if resident else " (one backward timestep of all pipelined LSTM layers per launch)")),
                                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                    "avg_launch_us": ms * 1e3 / launches, "launches": launches,
                                    "algorithmic_bytes_per_launch": nbytes / launches,
-                                   "note": ("avg_launch_us is event-to-event over sampled runs of back-to-back dependent "
-                                            "launches, i.e. kernel time + the ~1.6 us kernel boundary + the events' own "
-                                            "cost; the kernel alone is `rocprof_kernel_avg_us` (profiles/)")}
+                                   "us_per_timestep": ms * 1e3 / tsteps,
+                                   "note": ("avg_launch_us is event-to-event over sampled brackets (kernel + its counter memset + "
+                                            "the events' own cost); the kernel alone is `rocprof_kernel_avg_us` (profiles/). "
+                                            "The resident kernel is bounded by its chain of dependent timesteps (hand-off of "
+                                            "the dG row between the workgroups of a layer), not by HBM: DESIGN.md section 3")}
                 try:   # the committed rocprofv3 --kernel-trace --stats summary of this command
                     import csv
 
-                    with open(os.path.join(ROOT, "profiles", "r01_bench_v12_kernel_stats.csv")) as f:
+                    with open(os.path.join(ROOT, "profiles", "r01_bench_v13_kernel_stats.csv")) as f:
                         for row in csv.DictReader(f):
-                            if "lstm_bwd_step_mfma" in row["Name"] and "Li8E" in row["Name"]:
+                            if kname in row["Name"] and ("Li32E" in row["Name"] if resident else "Li8E" in row["Name"]):
                                 out["roofline"]["rocprof_kernel_avg_us"] = float(row["AverageNs"]) / 1e3
                                 break
                 except Exception:

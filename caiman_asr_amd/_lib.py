@@ -119,8 +119,11 @@ _SIGS = {
     "caiman_lstm_wave_fwd": ([P, I32, I32, I64, I64, I32, I32, I32, ctypes.c_uint64, P], ctypes.c_int),
     "caiman_lstm_wave_bwd": ([P, I32, I32, I64, I64, I32, I32, I32, ctypes.c_uint64, P], ctypes.c_int),
     "caiman_lstm_dropout_mask": ([P, I64, ctypes.c_uint64, ctypes.c_uint64, F32, I32, P], ctypes.c_int),
+    "caiman_colsum_splits": ([I64, I64, I64], ctypes.c_int64),
+    "caiman_colsum": ([P, I64, I64, I64, I64, P, P, I64, I32, P], ctypes.c_int),
     "caiman_lstm_resident_mode": ([I32], ctypes.c_int),
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
+    "caiman_lstm_resident_launches": ([], ctypes.c_int64),
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),
@@ -256,12 +259,13 @@ class timed:
     """`with timed("name"):` brackets the enclosed launches with HIP events on the CURRENT stream
     (the stream the kernels are launched on) when timing is enabled; otherwise it is free."""
 
-    __slots__ = ("name", "start", "units", "nbytes")
+    __slots__ = ("name", "start", "units", "nbytes", "steps")
 
     def __init__(self, name, units=1, nbytes=0):
         self.name = name
         self.units = units      # kernel launches of the dominant kernel inside the bracket
         self.nbytes = nbytes    # algorithmic bytes moved inside the bracket
+        self.steps = units      # dependent timesteps inside the bracket (== units unless one launch covers several)
         self.start = None
 
     def __enter__(self):
@@ -274,17 +278,17 @@ class timed:
         if self.start is not None:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
-            timing.records.setdefault(self.name, []).append((self.start, end, self.units, self.nbytes))
+            timing.records.setdefault(self.name, []).append((self.start, end, self.units, self.nbytes, self.steps))
         return False
 
 
 def timing_summary():
-    """{name: (brackets, total_ms, kernel launches, algorithmic bytes)} scaled from the sampled brackets to all of
-    them; synchronises."""
+    """{name: (brackets, total_ms, kernel launches, algorithmic bytes, timesteps)} scaled from the sampled brackets
+    to all of them; synchronises."""
     torch.cuda.synchronize()
     out = {}
     for k, v in timing.records.items():
         scale = timing.seen.get(k, len(v)) / max(len(v), 1)
         out[k] = (timing.seen.get(k, len(v)), scale * sum(r[0].elapsed_time(r[1]) for r in v),
-                  scale * sum(r[2] for r in v), scale * sum(r[3] for r in v))
+                  scale * sum(r[2] for r in v), scale * sum(r[3] for r in v), scale * sum(r[4] for r in v))
     return out

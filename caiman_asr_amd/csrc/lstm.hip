@@ -753,10 +753,15 @@ template <typename T, bool HARD, int NKS>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
-  constexpr int H = NKS * 32, LDH = H + 8, HK = NKS / 2;   // HK: k-steps per wave and stage
+  // The dG row is streamed in NST stages of SW columns; two register sets keep two stages in flight, so the
+  // stream never drains between stages (with one set per stage the next loads left only after the LDS write).
+  constexpr int H = NKS * 32, NST = NKS >= 8 ? 8 : 4, SW = 4 * H / NST, LDW = SW + 8;
+  constexpr int HK = 2 * NKS / NST;          // k-steps per wave and stage (the two K-halves of a stage)
+  constexpr int PER = 32 * SW / 8 / 256;     // 16-byte pieces per thread and stage
+  static_assert(PER >= 1 && HK >= 1, "stage too narrow");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* buf = reinterpret_cast<T*>(smem);                                  // [2][32][LDH]
-  float* red = reinterpret_cast<float*>(buf + 2 * 32 * LDH);            // [kh 2][rt 2][ct 2][16 units][17]
+  T* buf = reinterpret_cast<T*>(smem);                                  // [2][32][LDW]
+  float* red = reinterpret_cast<float*>(buf + 2 * 32 * LDW);            // [kh 2][rt 2][ct 2][16 units][17]
   int* flag = reinterpret_cast<int*>(red + 8 * 16 * 17);
 
   const int slot = blockIdx.y, j = blockIdx.x;
@@ -770,15 +775,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   const int r = lane & 15, kq = lane >> 4;
   const int rt = wave & 1, kh = wave >> 1;
 
-  frag wreg[4][HK];
+  frag wreg[NST][HK];
   {
     const T* Rt = w.Rttile[slot];
     const int64_t blk = (int64_t)j * 2 + rt;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NST; ++q)
 #pragma unroll
       for (int i = 0; i < HK; ++i) {
-        const int sidx = q * NKS + kh * HK + i;
+        const int sidx = q * (2 * HK) + kh * HK + i;
         wreg[q][i] = *reinterpret_cast<const frag*>(Rt + ((blk * (4 * NKS) + sidx) * 16 + r) * 32 + 8 * kq);
       }
   }
@@ -796,7 +801,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   const float pd = w.drop_p[slot];
   const float inv_keep = 1.f / (1.f - pd);
   const int64_t d_st = w.d_st[slot], d_sb = w.d_sb[slot];
-  constexpr int PER = (32 * H / 8 + 255) / 256;
 
   for (int s = 0; s < nsteps; ++s) {
     const T* g = w.g[slot] - go * s;
@@ -823,37 +827,39 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
       __syncthreads();
       if (*flag) break;
       const __amdgpu_buffer_rsrc_t rs = res_rsrc(dG + go);   // dG of the step before: row t+1, [B][4H]
-      frag v[PER];
+      frag v[2][PER];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
-        if (b < B) v[i] = res_load16<T>(rs, (b * 4 * H + k8 * 8) * (int)sizeof(T));
-        else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[i][q] = static_cast<T>(0.f);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        T* bq = buf + (q & 1) * (32 * LDH);
+      for (int q0 = 0; q0 < 2; ++q0)
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-          const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
-          if (b < 32) *reinterpret_cast<frag*>(bq + b * LDH + k8 * 8) = v[i];
+          const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
+          if (b < B) v[q0][i] = res_load16<T>(rs, (b * 4 * H + q0 * SW + k8 * 8) * (int)sizeof(T));
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[q0][i][e] = static_cast<T>(0.f);
+          }
         }
-        if (q < 3) {
+#pragma unroll
+      for (int q = 0; q < NST; ++q) {
+        T* bq = buf + (q & 1) * (32 * LDW);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
+          *reinterpret_cast<frag*>(bq + b * LDW + k8 * 8) = v[q & 1][i];
+        }
+        if (q + 2 < NST) {
 #pragma unroll
           for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
-            if (b < B) v[i] = res_load16<T>(rs, (b * 4 * H + (q + 1) * H + k8 * 8) * (int)sizeof(T));
+            const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
+            if (b < B) v[q & 1][i] = res_load16<T>(rs, (b * 4 * H + (q + 2) * SW + k8 * 8) * (int)sizeof(T));
           }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < HK; ++i) {
           const int kk = (kh * HK + i) * 32 + kq * 8;
-          const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDH + kk);
-          const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDH + kk);
+          const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDW + kk);
+          const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + kk);
           acc[0] = mfma16(wreg[q][i], b0, acc[0]);
           acc[1] = mfma16(wreg[q][i], b1, acc[1]);
         }
@@ -972,10 +978,32 @@ struct ResState {
   int next = 0;
   int cus = 0;
   bool ok = false;
+  // Two resident grids on different streams could each hold part of the chip and wait for the rest: a resident
+  // launch on another stream than the previous one first waits for that one's completion event.
+  hipEvent_t done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
 };
 std::mutex g_res_mu;
 ResState g_res[16];
-std::atomic<int> g_res_mode{0};
+std::atomic<int> g_res_mode{1};
+std::atomic<long long> g_res_launches{0};
+
+// counter block for one launch; orders the launch behind a resident launch still running on another stream
+unsigned* res_begin(ResState* st, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  unsigned* sync = st->sync[st->next];
+  st->next = (st->next + 1) % kResPool;
+  if (st->has_last && st->last_stream != s) (void)hipStreamWaitEvent(s, st->done, 0);
+  return sync;
+}
+void res_end(ResState* st, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  (void)hipEventRecord(st->done, s);
+  st->last_stream = s;
+  st->has_last = true;
+  g_res_launches.fetch_add(1, std::memory_order_relaxed);
+}
 
 ResState* res_state() {
   int dev = 0;
@@ -990,6 +1018,7 @@ ResState* res_state() {
     *st.fail_host = 0;
     for (int i = 0; i < kResPool; ++i)
       if (hipMalloc(reinterpret_cast<void**>(&st.sync[i]), kResSyncBytes) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return nullptr;
     st.ok = true;
   }
   return &st;
@@ -1009,12 +1038,7 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
-  unsigned* sync;
-  {
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    sync = st->sync[st->next];
-    st->next = (st->next + 1) % kResPool;
-  }
+  unsigned* sync = res_begin(st, s);
   if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = res_fwd_lds<T>((int)H);
@@ -1041,12 +1065,16 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
     default: CAIMAN_RES(32); break;
   }
 #undef CAIMAN_RES
+  res_end(st, s);
   *err = check_launch("lstm resident forward");
   return true;
 }
 
 template <typename T>
-inline size_t res_bwd_lds(int H) { return (size_t)(2 * 32 * (H + 8)) * sizeof(T) + (size_t)8 * 16 * 17 * sizeof(float) + 16; }
+inline size_t res_bwd_lds(int H) {
+  const int nst = H / 32 >= 8 ? 8 : 4;   // as in lstm_bwd_resident
+  return (size_t)(2 * 32 * (4 * H / nst + 8)) * sizeof(T) + (size_t)8 * 16 * 17 * sizeof(float) + 16;
+}
 
 template <typename T, bool HARD>
 bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
@@ -1063,12 +1091,7 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
-  unsigned* sync;
-  {
-    std::lock_guard<std::mutex> lk(g_res_mu);
-    sync = st->sync[st->next];
-    st->next = (st->next + 1) % kResPool;
-  }
+  unsigned* sync = res_begin(st, s);
   if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = res_bwd_lds<T>((int)H);
@@ -1095,6 +1118,7 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
     default: CAIMAN_RES(32); break;
   }
 #undef CAIMAN_RES
+  res_end(st, s);
   *err = check_launch("lstm resident backward");
   return true;
 }
@@ -1205,11 +1229,17 @@ extern "C" int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uin
   return check_launch("caiman_lstm_dropout_mask");
 }
 
-// Weight-resident chunk kernels (above): 0 = per-timestep launches only, 1 = one launch per call where the shapes
+// Weight-resident chunk kernels (above): 0 = per-timestep launches only, 1 (default) = one launch per call where the shapes
 // allow it (interleaved gates, B <= 32, one hidden size per call, slots x H/32 workgroups <= CUs).  Returns the
 // previous mode.
 extern "C" int caiman_lstm_resident_mode(int mode) {
   return caiman::g_res_mode.exchange(mode ? 1 : 0);
+}
+
+// Wave calls served by a resident launch since the library was loaded (callers that account launches and bytes
+// compare the value before and after a call).
+extern "C" int64_t caiman_lstm_resident_launches(void) {
+  return (int64_t)caiman::g_res_launches.load(std::memory_order_relaxed);
 }
 
 // Number of resident-kernel workgroups that gave up waiting for their peers since the library was loaded (0 in a

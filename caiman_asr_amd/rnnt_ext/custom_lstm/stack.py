@@ -20,6 +20,7 @@ from typing import List, Optional
 import torch
 
 from caiman_asr_amd import _lib
+from caiman_asr_amd.rnnt_ext.cuda.colsum import colsum
 from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 
 CHUNK = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK", "32"))  # timesteps per pipeline chunk, shallow stacks
@@ -150,9 +151,13 @@ class StackFunction(torch.autograd.Function):
                                           drop if masked else 0.0, 0))
             arr = (_lib.FwdSlot * len(slots))(*slots)
             n_launch = max(s_.nsteps for s_ in slots)
-            with _lib.timed("lstm_fwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
+            with _lib.timed("lstm_fwd", n_launch, sb * sum(s_.nsteps for s_ in slots)) as tm:
+                r0 = lib.caiman_lstm_resident_launches() if tm.start is not None else 0
                 _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
                                                     tag, int(hard), INTERLEAVED, seed, st))
+                if tm.start is not None and lib.caiman_lstm_resident_launches() != r0:   # weights read once per slot
+                    tm.units = 1
+                    tm.nbytes -= sum(s_.nsteps - 1 for s_ in slots) * 4 * H * H * G.element_size()
         saved = [x, G, Y, Cs, *Wp, *Rp]
         if YM is not None:
             saved.append(YM)
@@ -238,9 +243,13 @@ class StackFunction(torch.autograd.Function):
                                           p_slot, (l * T + thi) * row))
             arr = (_lib.BwdSlot * len(slots))(*slots)
             n_launch = max(s_.nsteps for s_ in slots)
-            with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)):
+            with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)) as tm:
+                r0 = lib.caiman_lstm_resident_launches() if tm.start is not None else 0
                 _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(arr, ctypes.c_void_p), len(slots), n_launch, B, H,
                                                     tag, int(hard), INTERLEAVED, seed, st))
+                if tm.start is not None and lib.caiman_lstm_resident_launches() != r0:   # weights read once per slot
+                    tm.units = 1
+                    tm.nbytes -= sum(s_.nsteps - 1 for s_ in slots) * 4 * H * H * G.element_size()
 
         def weight_grads(l):
             dg = dG[l].view(T * B, 4 * H)
@@ -248,7 +257,7 @@ class StackFunction(torch.autograd.Function):
                 xin = x.detach().flatten(0, 1).to(dt)
             else:
                 xin = (YM[l - 1] if drop > 0.0 else Y[l - 1, 1:]).reshape(T * B, H)
-            dB = _unperm_rows(dg.sum(0), H)
+            dB = _unperm_rows(colsum(dg), H)
             return [_unperm_rows(torch.matmul(dg.t(), xin), H),
                     _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
 

@@ -177,15 +177,26 @@ int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n
                          uint64_t seed, caiman_stream_t stream);
 int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base, float p, int dtype,
                              caiman_stream_t stream);
-/* Weight-resident variant of the wave calls (same slots, same results up to fp32 summation order): with mode 1 a
- * wave call whose shapes allow it (interleaved gates, B <= 32, one hidden size, n_slots * H/32 workgroups not more
+/* Weight-resident variant of the wave calls (same slots, same results up to fp32 summation order): with mode 1
+ * (the default) a wave call whose shapes allow it (interleaved gates, B <= 32, one hidden size, n_slots * H/32 workgroups not more
  * than the device has CUs) runs ALL its timesteps in one launch, each workgroup keeping its rows of R in registers
  * and the workgroups of a slot meeting at a device counter once per timestep; other calls keep the per-timestep
  * launches.  Replaces the same time loop (training/lib/csrc/lstm.cu:214-346).  caiman_lstm_resident_mode returns the
  * previous mode; caiman_lstm_resident_failures counts workgroups that timed out waiting (0 in a healthy process; a
- * non-zero value invalidates the results of that launch) and does not synchronise the device. */
+ * non-zero value invalidates the results of that launch) and does not synchronise the device;
+ * caiman_lstm_resident_launches counts the wave calls served this way. */
 int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
+int64_t caiman_lstm_resident_launches(void);
+
+/* Column sums of tall row-major matrices, out[b][c] = sum_r x[b][r][c]: the bias gradients of the LSTM layers
+ * (training/lib/src/rnnt_ext/custom_lstm/lstm.py:57, `dB = dG.sum([0, 1])`) and of linear layers.  f16 / bf16 in,
+ * fp32 accumulation, result in the input type; deterministic (two passes, no atomics).  x rows are contiguous
+ * (row pitch = cols, a multiple of 8), matrix b starts at x + b * batch_stride; partial is a caller-provided fp32
+ * scratch of batch * splits * cols elements with splits = caiman_colsum_splits(batch, rows, cols) (or any 1..65535). */
+int64_t caiman_colsum_splits(int64_t batch, int64_t rows, int64_t cols);
+int caiman_colsum(const void* x, int64_t batch, int64_t rows, int64_t cols, int64_t batch_stride, void* out,
+                  float* partial, int64_t splits, int dtype, caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not

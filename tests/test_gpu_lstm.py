@@ -173,6 +173,7 @@ def test_layer_pipelined_stack_equals_per_layer_schedule(T, B, I, H, L, dtype):
     """The chunked layer pipeline (custom_lstm/stack.py) runs the same kernels on the same operands in a
     different order, so with dropout off it must reproduce the layer-by-layer schedule: outputs, states and
     every gradient (bit-exact up to the summation order of the final weight-gradient GEMMs)."""
+    from caiman_asr_amd import _lib
     from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
 
     torch.manual_seed(T + H)
@@ -183,14 +184,18 @@ def test_layer_pipelined_stack_equals_per_layer_schedule(T, B, I, H, L, dtype):
     c0 = torch.randn(L, B, H, device=DEV) * 0.3
     w = torch.randn(T, B, H, device=DEV)
     outs = []
-    for xin, pipe in ((x1, True), (x2, False)):
-        m.pipeline_layers = pipe
-        m.zero_grad()
-        with torch.autocast("cuda", dtype=dtype):
-            y, (hn, cn), (ah, ac) = m(xin, (h0, c0))
-        (y.float() * w).sum().backward()
-        outs.append((y.float(), hn.float(), cn.float(), ah.float(), ac.float(), xin.grad.clone(),
-                     [p.grad.clone() for p in m.parameters()]))
+    prev = _lib.lib().caiman_lstm_resident_mode(0)   # the same KERNELS in another order: per-timestep launches on both sides
+    try:
+        for xin, pipe in ((x1, True), (x2, False)):
+            m.pipeline_layers = pipe
+            m.zero_grad()
+            with torch.autocast("cuda", dtype=dtype):
+                y, (hn, cn), (ah, ac) = m(xin, (h0, c0))
+            (y.float() * w).sum().backward()
+            outs.append((y.float(), hn.float(), cn.float(), ah.float(), ac.float(), xin.grad.clone(),
+                         [p.grad.clone() for p in m.parameters()]))
+    finally:
+        _lib.lib().caiman_lstm_resident_mode(prev)
     a, b = outs
     for i in range(5):
         assert torch.equal(a[i], b[i]), i
@@ -278,3 +283,118 @@ def test_fused_interlayer_dropout_matches_explicit_masks():
     assert torch.allclose(x1.grad, x2.grad, atol=3e-2 * x2.grad.abs().max().item())
     for a, p_ in zip(g1, m.parameters()):
         assert torch.allclose(a, p_.grad, atol=3e-2 * (p_.grad.abs().max().item() + 1e-6))
+
+
+def _run_stack(m, x, h0, c0, w, dtype, mode):
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    prev = lib.caiman_lstm_resident_mode(mode)
+    n0 = lib.caiman_lstm_resident_launches()
+    try:
+        m.zero_grad()
+        xin = x.detach().clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=dtype):
+            y, (hn, cn), (ah, ac) = m(xin, (h0, c0))
+        (y.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        out = [y.float(), hn.float(), cn.float(), ah.float(), ac.float(), xin.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    finally:
+        lib.caiman_lstm_resident_mode(prev)
+    return out, lib.caiman_lstm_resident_launches() - n0
+
+
+@pytest.mark.parametrize("T,B,I,H,L,p", [(40, 3, 16, 64, 2, 0.0), (70, 32, 48, 128, 3, 0.0), (150, 17, 64, 256, 4, 0.0),
+                                         (90, 8, 64, 512, 3, 0.3), (50, 32, 64, 768, 2, 0.2), (70, 32, 64, 1024, 3, 0.0)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_resident_chunk_kernels_match_step_kernels(T, B, I, H, L, p, dtype):
+    """csrc/lstm.hip, weight-resident chunk kernels: one launch runs every timestep of a pipeline tick, the
+    workgroups of a layer handing h (forward) / dG (backward) to each other through memory once per timestep.  Same
+    arithmetic as the per-timestep kernels except for the fp32 summation order of the recurrent product, so outputs,
+    states and gradients agree to the storage type's resolution; a hand-off that read stale bytes would show up as a
+    difference between two resident runs, which must be bit-identical; no workgroup may have timed out."""
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    if dtype == torch.float16 and H > 256:
+        pytest.skip("f16 covered at the small sizes")
+    torch.manual_seed(T + H)
+    m = CustomLSTM(I, H, L, dropout=p, device=DEV)
+    x = torch.randn(T, B, I, device=DEV)
+    h0 = torch.randn(L, B, H, device=DEV) * 0.3
+    c0 = torch.randn(L, B, H, device=DEV) * 0.3
+    w = torch.randn(T, B, H, device=DEV)
+    res = {}
+    for name, mode in (("step", 0), ("res1", 1), ("res2", 1)):
+        torch.manual_seed(7)
+        res[name], launches = _run_stack(m, x, h0, c0, w, dtype, mode)
+        assert (launches > 0) == (mode == 1), (name, launches)
+    assert _lib.lib().caiman_lstm_resident_failures() == 0
+    for a, b in zip(res["res1"], res["res2"]):
+        assert torch.equal(a, b)
+    eps = 8e-3 if dtype == torch.bfloat16 else 2e-3
+    for i, (a, b) in enumerate(zip(res["res1"], res["step"])):
+        scale = b.abs().max().item() + 1e-6
+        assert torch.allclose(a, b, atol=(eps if i < 5 else 2e-2) * scale, rtol=0), (i, (a - b).abs().max().item() / scale)
+    if p > 0:
+        assert ((res["res1"][0] == 0) == (res["step"][0] == 0)).all()   # same dropout pattern
+
+
+def test_resident_kernels_under_uneven_load_and_fallbacks():
+    """Hand-offs must not depend on timing or placement: repeat a resident run while another stream keeps part of
+    the chip busy with copies and compare bit for bit with the quiet run.  Shapes the resident kernels do not take
+    (B > 32) keep the per-timestep launches."""
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    T, B, I, H, L = 96, 32, 64, 512, 4
+    torch.manual_seed(3)
+    m = CustomLSTM(I, H, L, device=DEV)
+    x = torch.randn(T, B, I, device=DEV)
+    h0 = torch.zeros(L, B, H, device=DEV)
+    c0 = torch.zeros(L, B, H, device=DEV)
+    w = torch.randn(T, B, H, device=DEV)
+    quiet, n = _run_stack(m, x, h0, c0, w, torch.bfloat16, 1)
+    assert n > 0
+    side = torch.cuda.Stream()
+    src = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                dst.copy_(src, non_blocking=True)
+        busy, _ = _run_stack(m, x, h0, c0, w, torch.bfloat16, 1)
+        side.synchronize()
+        for a, b in zip(quiet, busy):
+            assert torch.equal(a, b)
+    assert _lib.lib().caiman_lstm_resident_failures() == 0
+    xb = torch.randn(T, 40, I, device=DEV)
+    _, n = _run_stack(m, xb, torch.zeros(L, 40, H, device=DEV), torch.zeros(L, 40, H, device=DEV),
+                      torch.randn(T, 40, H, device=DEV), torch.bfloat16, 1)
+    assert n == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 17, 64), (1, 17803, 4096), (6, 8901, 4096), (2, 3333, 2048), (1, 40, 8704), (3, 1, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_colsum_matches_fp64_sum(shape, dtype):
+    """csrc/colsum.hip (bias gradients, reference lstm.py:57 `dG.sum([0, 1])`): fp32 accumulation, one rounding to
+    the storage type, bit-reproducible from run to run."""
+    from caiman_asr_amd.rnnt_ext.cuda.colsum import colsum
+
+    torch.manual_seed(sum(shape))
+    b, r, c = shape
+    x = (torch.randn(b, r, c, device=DEV) * 0.5).to(dtype)
+    ref = x.double().sum(1)
+    got = colsum(x)
+    assert got.shape == (b, c) and got.dtype == dtype
+    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10) * ref.abs().max().item() + 1e-3 * r ** 0.5 * 2.0 ** -10
+    assert (got.double() - ref).abs().max().item() <= tol
+    assert torch.equal(got, colsum(x))
+    assert torch.equal(colsum(x[0]), got[0])
+    # a strided batch (layers of one activation tensor) and the fallback for shapes outside the kernel's contract
+    big = (torch.randn(b, r + 3, c, device=DEV)).to(dtype)
+    view = big[:, 1:r + 1]
+    if view.stride(1) == c:
+        assert torch.allclose(colsum(view).float(), view.float().sum(1), atol=tol * 4 + 1e-2, rtol=2e-2)
+    odd = torch.randn(5, 7, device=DEV)
+    assert torch.allclose(colsum(odd), odd.sum(0))
