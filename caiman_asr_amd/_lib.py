@@ -119,8 +119,6 @@ _SIGS = {
     "caiman_lstm_wave_fwd": ([P, I32, I32, I64, I64, I32, I32, I32, ctypes.c_uint64, P], ctypes.c_int),
     "caiman_lstm_wave_bwd": ([P, I32, I32, I64, I64, I32, I32, I32, ctypes.c_uint64, P], ctypes.c_int),
     "caiman_lstm_dropout_mask": ([P, I64, ctypes.c_uint64, ctypes.c_uint64, F32, I32, P], ctypes.c_int),
-    "caiman_colsum_splits": ([I64, I64, I64], ctypes.c_int64),
-    "caiman_colsum": ([P, I64, I64, I64, I64, P, P, I64, I32, P], ctypes.c_int),
     "caiman_lstm_resident_mode": ([I32], ctypes.c_int),
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
     "caiman_lstm_resident_launches": ([], ctypes.c_int64),

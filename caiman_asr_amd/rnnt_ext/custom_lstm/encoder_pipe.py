@@ -18,7 +18,6 @@ import ctypes
 import torch
 
 from caiman_asr_amd import _lib
-from caiman_asr_amd.rnnt_ext.cuda.colsum import colsum
 from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 from caiman_asr_amd.rnnt_ext.custom_lstm import stack
 from caiman_asr_amd.rnnt_ext.custom_lstm.stack import INTERLEAVED, _pad32, _perm_rows, _Scratch, _unperm_rows
@@ -381,7 +380,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             post_R = torch.bmm(dgb.transpose(1, 2), Yb[:, :T2].reshape(Lb, T2 * B, H))
             xin = (YMb[:Lb - 1] if pl[La] > 0.0 else Yb[:Lb - 1, 1:]).reshape(Lb - 1, T2 * B, H)
             post_W = torch.bmm(dgb[1:].transpose(1, 2), xin)
-            post_b = colsum(dgb)
+            post_b = dgb.sum(1)
         per_layer = [None] * L
         for l in (reversed(range(L)) if direct else range(L)):
             T, hl = Tl[l], Hl[l]
@@ -393,7 +392,7 @@ class EncoderPipeFunction(torch.autograd.Function):
                 g4 = [gW, post_R[m], dB, dB]
             else:
                 yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
-                dB = colsum(dg)
+                dB = dg.sum(0)
                 g4 = [torch.matmul(dg.t(), layer_input(l)), torch.matmul(dg.t(), yprev), dB, dB]
             if direct:
                 for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], g4):

@@ -20,7 +20,6 @@ from typing import List, Optional
 import torch
 
 from caiman_asr_amd import _lib
-from caiman_asr_amd.rnnt_ext.cuda.colsum import colsum
 from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 
 CHUNK = int(__import__("os").environ.get("CAIMAN_LSTM_CHUNK", "32"))  # timesteps per pipeline chunk, shallow stacks
@@ -257,7 +256,7 @@ class StackFunction(torch.autograd.Function):
                 xin = x.detach().flatten(0, 1).to(dt)
             else:
                 xin = (YM[l - 1] if drop > 0.0 else Y[l - 1, 1:]).reshape(T * B, H)
-            dB = _unperm_rows(colsum(dg), H)
+            dB = _unperm_rows(dg.sum(0), H)
             return [_unperm_rows(torch.matmul(dg.t(), xin), H),
                     _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
 

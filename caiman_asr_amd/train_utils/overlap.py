@@ -11,8 +11,6 @@ import os
 import torch
 import torch.nn.functional as F
 
-from caiman_asr_amd.rnnt_ext.cuda.colsum import colsum
-
 _side = {}
 _pending = False
 _deferred = []   # closures that launch side-stream work; run by flush_deferred()
@@ -103,7 +101,7 @@ class _LinearOverlapped(torch.autograd.Function):
                 x2 = x.reshape(-1, x.shape[-1]).to(dy.dtype)
                 _accumulate(weight, torch.matmul(dy2.t(), x2))
                 if bias is not None:
-                    _accumulate(bias, colsum(dy2))
+                    _accumulate(bias, dy2.sum(0))
             for t in (dy, x):
                 t.record_stream(side)
             _pending = True
@@ -145,7 +143,7 @@ class _LinearTransposedBackward(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.mm(dy2.t(), x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2).to(weight.dtype)
+            db = dy2.sum(0).to(weight.dtype)
         return dx, dw, db
 
 

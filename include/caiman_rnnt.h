@@ -189,15 +189,6 @@ int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
 int64_t caiman_lstm_resident_launches(void);
 
-/* Column sums of tall row-major matrices, out[b][c] = sum_r x[b][r][c]: the bias gradients of the LSTM layers
- * (training/lib/src/rnnt_ext/custom_lstm/lstm.py:57, `dB = dG.sum([0, 1])`) and of linear layers.  f16 / bf16 in,
- * fp32 accumulation, result in the input type; deterministic (two passes, no atomics).  x rows are contiguous
- * (row pitch = cols, a multiple of 8), matrix b starts at x + b * batch_stride; partial is a caller-provided fp32
- * scratch of batch * splits * cols elements with splits = caiman_colsum_splits(batch, rows, cols) (or any 1..65535). */
-int64_t caiman_colsum_splits(int64_t batch, int64_t rows, int64_t cols);
-int caiman_colsum(const void* x, int64_t batch, int64_t rows, int64_t cols, int64_t batch_stride, void* out,
-                  float* partial, int64_t splits, int dtype, caiman_stream_t stream);
-
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
  * vendored; call sites training/caiman_asr_train/rnnt/model.py:228-238,425-434; CPU

@@ -372,29 +372,3 @@ def test_resident_kernels_under_uneven_load_and_fallbacks():
     _, n = _run_stack(m, xb, torch.zeros(L, 40, H, device=DEV), torch.zeros(L, 40, H, device=DEV),
                       torch.randn(T, 40, H, device=DEV), torch.bfloat16, 1)
     assert n == 0
-
-
-@pytest.mark.parametrize("shape", [(1, 17, 64), (1, 17803, 4096), (6, 8901, 4096), (2, 3333, 2048), (1, 40, 8704), (3, 1, 8)])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_colsum_matches_fp64_sum(shape, dtype):
-    """csrc/colsum.hip (bias gradients, reference lstm.py:57 `dG.sum([0, 1])`): fp32 accumulation, one rounding to
-    the storage type, bit-reproducible from run to run."""
-    from caiman_asr_amd.rnnt_ext.cuda.colsum import colsum
-
-    torch.manual_seed(sum(shape))
-    b, r, c = shape
-    x = (torch.randn(b, r, c, device=DEV) * 0.5).to(dtype)
-    ref = x.double().sum(1)
-    got = colsum(x)
-    assert got.shape == (b, c) and got.dtype == dtype
-    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10) * ref.abs().max().item() + 1e-3 * r ** 0.5 * 2.0 ** -10
-    assert (got.double() - ref).abs().max().item() <= tol
-    assert torch.equal(got, colsum(x))
-    assert torch.equal(colsum(x[0]), got[0])
-    # a strided batch (layers of one activation tensor) and the fallback for shapes outside the kernel's contract
-    big = (torch.randn(b, r + 3, c, device=DEV)).to(dtype)
-    view = big[:, 1:r + 1]
-    if view.stride(1) == c:
-        assert torch.allclose(colsum(view).float(), view.float().sum(1), atol=tol * 4 + 1e-2, rtol=2e-2)
-    odd = torch.randn(5, 7, device=DEV)
-    assert torch.allclose(colsum(odd), odd.sum(0))
