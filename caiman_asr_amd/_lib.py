@@ -122,6 +122,7 @@ _SIGS = {
     "caiman_lstm_resident_mode": ([I32], ctypes.c_int),
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
     "caiman_lstm_resident_launches": ([], ctypes.c_int64),
+    "caiman_lstm_resident_profile": ([P], ctypes.c_int),
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),
@@ -184,7 +185,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = restype
         _lib = L
-        if os.environ.get("CAIMAN_LSTM_RESIDENT", "") in ("0", "1"):   # weight-resident LSTM chunk kernels (csrc/lstm.hip)
+        if os.environ.get("CAIMAN_LSTM_RESIDENT", "") in ("0", "1", "2"):   # weight-resident LSTM chunk kernels (csrc/lstm.hip)
             L.caiman_lstm_resident_mode(int(os.environ["CAIMAN_LSTM_RESIDENT"]))
     return _lib
 

@@ -509,6 +509,18 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_mfma(BwdSlots<T> w, int st
   dC[(int64_t)be * H + ne] = dc * gf;
 }
 
+// Soft activations on the hardware transcendental units (v_exp_f32, v_rcp_f32) for the resident kernels, where one
+// lane updates four cells per timestep inside the dependent chain: the library expf / tanhf cost 2.6 us of a 7 us
+// forward timestep (phase timers, tools/lstm_resident_bench.py).  Error ~1e-6 relative, far below the storage
+// type's resolution; hard activations are plain arithmetic and stay as they are.
+template <bool HARD>
+struct FastAct : Act<float, HARD> {};
+template <>
+struct FastAct<false> : Act<float, false> {
+  __device__ __forceinline__ static float sigm(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+  __device__ __forceinline__ static float tanhv(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * z)); }
+};
+
 // ===========================================================================
 // Weight-resident chunk kernels.
 //
@@ -569,7 +581,10 @@ __device__ __forceinline__ void res_store16(const V& val, __amdgpu_buffer_rsrc_t
   __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);
 }
 
-template <typename T, bool HARD, int NKS>
+// PROF: thread 0 of workgroup (0, slot 0) adds the 10 ns ticks it spends per phase to fail_host[kResProfFwd + ..]
+// (wait for the peers | h into LDS | MFMA + cell update | drain of the stores + barrier) and the timestep count.
+constexpr int kResProfFwd = 2, kResProfBwd = 8;
+template <typename T, bool HARD, int NKS, bool PROF>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
@@ -628,6 +643,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
   const float pd = w.drop_p[slot];
   const float inv_keep = 1.f / (1.f - pd);
 
+  const bool prof = PROF && tid == 0 && slot == 0 && j == 0;
+  long long tp[5] = {0, 0, 0, 0, 0}, pt = 0;
+  if (prof) pt = wall_clock64();
+#define CAIMAN_PROF_MARK(i)                  \
+  if (prof) {                                \
+    const long long now_ = wall_clock64();   \
+    tp[i] += now_ - pt;                      \
+    pt = now_;                               \
+  }
   for (int s = 0; s < nsteps; ++s) {
     T* g = w.g[slot] + go * s;
     if (s + 1 < nsteps) {   // next step's pre-activations: independent of h, in flight across the wait
@@ -645,6 +669,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __syncthreads();
     if (*flag) break;
+    CAIMAN_PROF_MARK(0)
     // h of this step: row s of y, [B][H] row-major -> LDS (rows >= B are zero).  Every load of handed-off bytes is
     // an sc1 load to registers, which stands in for the agent acquire (visibility table, first row).
     {
@@ -667,6 +692,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
       }
     }
     __syncthreads();
+    CAIMAN_PROF_MARK(1)
     f32x4 acc[2][2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -691,11 +717,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
         const float pf = static_cast<float>(gcur[rt][ct][1]) + acc[rt][ct][1];
         const float pg = static_cast<float>(gcur[rt][ct][2]) + acc[rt][ct][2];
         const float po = static_cast<float>(gcur[rt][ct][3]) + acc[rt][ct][3];
-        const float ig = Act<float, HARD>::sigm(pi), fg = Act<float, HARD>::sigm(pf);
-        const float gg = Act<float, HARD>::tanhv(pg), og = Act<float, HARD>::sigm(po);
+        const float ig = FastAct<HARD>::sigm(pi), fg = FastAct<HARD>::sigm(pf);
+        const float gg = FastAct<HARD>::tanhv(pg), og = FastAct<HARD>::sigm(po);
         const float c = ig * gg + fg * creg[rt][ct];
         const T cv = static_cast<T>(c);
-        const T yv = static_cast<T>(og * Act<float, HARD>::tanhv(c));
+        const T yv = static_cast<T>(og * FastAct<HARD>::tanhv(c));
         creg[rt][ct] = static_cast<float>(cv);
         trh[b * 8 + ul] = yv;
         trc[b * 8 + ul] = cv;
@@ -736,9 +762,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
         }
       }
     }
+    CAIMAN_PROF_MARK(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CAIMAN_PROF_MARK(3)
+  }
+  if (prof) {
+    for (int i = 0; i < 4; ++i)
+      __hip_atomic_fetch_add(fail_host + kResProfFwd + i, (unsigned)tp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfFwd + 4, (unsigned)nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -749,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
 // multiplying its half of a stage while the next one is in flight; the two K-halves meet in LDS and 256 threads
 // finish 4 units of one batch row each (32-byte dG pieces, written through for the next step's readers).
 // dC stays in registers across the launch.
-template <typename T, bool HARD, int NKS>
+template <typename T, bool HARD, int NKS, bool PROF>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
@@ -775,6 +808,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   const int r = lane & 15, kq = lane >> 4;
   const int rt = wave & 1, kh = wave >> 1;
 
+  // Workgroups j, j+8, j+16, j+24 of a slot usually share an XCD (blocks are dealt round-robin): each walks the
+  // stages from a different quarter of the row, so that what one has pulled into the XCD's L2 the other three find
+  // there.  Placement only changes the speed; the sum over K is in a per-workgroup, fixed order either way.
+  const int rot = ((j >> 3) & 3) * (NST / 4);
   frag wreg[NST][HK];
   {
     const T* Rt = w.Rttile[slot];
@@ -783,7 +820,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
     for (int q = 0; q < NST; ++q)
 #pragma unroll
       for (int i = 0; i < HK; ++i) {
-        const int sidx = q * (2 * HK) + kh * HK + i;
+        const int sidx = ((q + rot) % NST) * (2 * HK) + kh * HK + i;
         wreg[q][i] = *reinterpret_cast<const frag*>(Rt + ((blk * (4 * NKS) + sidx) * 16 + r) * 32 + 8 * kq);
       }
   }
@@ -802,6 +839,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   const float inv_keep = 1.f / (1.f - pd);
   const int64_t d_st = w.d_st[slot], d_sb = w.d_sb[slot];
 
+  const bool prof = PROF && tid == 0 && slot == 0 && j == 0;
+  long long tp[5] = {0, 0, 0, 0, 0}, pt = 0;
+  if (prof) pt = wall_clock64();
   for (int s = 0; s < nsteps; ++s) {
     const T* g = w.g[slot] - go * s;
     const T* c_prev = w.c[slot] - so * s;
@@ -826,6 +866,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __syncthreads();
       if (*flag) break;
+      CAIMAN_PROF_MARK(0)
       const __amdgpu_buffer_rsrc_t rs = res_rsrc(dG + go);   // dG of the step before: row t+1, [B][4H]
       frag v[2][PER];
 #pragma unroll
@@ -833,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
           const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
-          if (b < B) v[q0][i] = res_load16<T>(rs, (b * 4 * H + q0 * SW + k8 * 8) * (int)sizeof(T));
+          if (b < B) v[q0][i] = res_load16<T>(rs, (b * 4 * H + ((q0 + rot) % NST) * SW + k8 * 8) * (int)sizeof(T));
           else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[q0][i][e] = static_cast<T>(0.f);
@@ -851,7 +892,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
 #pragma unroll
           for (int i = 0; i < PER; ++i) {
             const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
-            if (b < B) v[q & 1][i] = res_load16<T>(rs, (b * 4 * H + (q + 2) * SW + k8 * 8) * (int)sizeof(T));
+            if (b < B) v[q & 1][i] = res_load16<T>(rs, (b * 4 * H + ((q + 2 + rot) % NST) * SW + k8 * 8) * (int)sizeof(T));
           }
         }
         __syncthreads();
@@ -865,6 +906,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
         }
       }
     }
+    CAIMAN_PROF_MARK(1)
     // C layout: column lane&15 = batch row of the column tile, row kq*4 + reg = unit of the row tile
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -887,12 +929,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
         const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
         const float gg = static_cast<float>(gv[(q & 1) * 4 + 2]), go_ = static_cast<float>(gv[(q & 1) * 4 + 3]);
         const float cp = static_cast<float>(cpv[q]), cc = static_cast<float>(ccv[q]);
-        const float ct = Act<float, HARD>::tanhv(cc);
-        const float dc = dy * go_ * Act<float, HARD>::tanh_prime(ct) + dcs[q];
-        vI[q] = static_cast<T>(dc * gg * Act<float, HARD>::sigm_prime(gi));
-        vF[q] = static_cast<T>(dc * cp * Act<float, HARD>::sigm_prime(gf));
-        vG[q] = static_cast<T>(dc * gi * Act<float, HARD>::tanh_prime(gg));
-        vO[q] = static_cast<T>(dy * ct * Act<float, HARD>::sigm_prime(go_));
+        const float ct = FastAct<HARD>::tanhv(cc);
+        const float dc = dy * go_ * FastAct<HARD>::tanh_prime(ct) + dcs[q];
+        vI[q] = static_cast<T>(dc * gg * FastAct<HARD>::sigm_prime(gi));
+        vF[q] = static_cast<T>(dc * cp * FastAct<HARD>::sigm_prime(gf));
+        vG[q] = static_cast<T>(dc * gi * FastAct<HARD>::tanh_prime(gg));
+        vO[q] = static_cast<T>(dy * ct * FastAct<HARD>::sigm_prime(go_));
         dcs[q] = dc * gf;
       }
       frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
@@ -912,11 +954,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
         *reinterpret_cast<f32x4*>(w.dC[slot] + eoff) = dv;
       }
     }
+    CAIMAN_PROF_MARK(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CAIMAN_PROF_MARK(3)
+  }
+  if (prof) {
+    for (int i = 0; i < 4; ++i)
+      __hip_atomic_fetch_add(fail_host + kResProfBwd + i, (unsigned)tp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfBwd + 4, (unsigned)nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+#undef CAIMAN_PROF_MARK
 
 template <typename T>
 constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value;
@@ -1015,7 +1065,7 @@ ResState* res_state() {
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
     st.cus = prop.multiProcessorCount;
     if (hipHostMalloc(reinterpret_cast<void**>(&st.fail_host), 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-    *st.fail_host = 0;
+    for (int i = 0; i < 16; ++i) st.fail_host[i] = 0;
     for (int i = 0; i < kResPool; ++i)
       if (hipMalloc(reinterpret_cast<void**>(&st.sync[i]), kResSyncBytes) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -1044,15 +1094,17 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
   do {                                                                                                               \
-    auto kern = lstm_fwd_resident<T, HARD, NKV>;                                                                     \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
+    auto kern = g_res_mode.load(std::memory_order_relaxed) == 2 ? lstm_fwd_resident<T, HARD, NKV, true>               \
+                                                                : lstm_fwd_resident<T, HARD, NKV, false>;             \
+    static bool attr_set[2] = {false, false};                                                                        \
+    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2];                                     \
+    if (!attr_done) {                                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)res_fwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
         *err = check_launch("lstm resident attribute");                                                              \
         return true;                                                                                                 \
       }                                                                                                              \
-      attr_set = true;                                                                                               \
+      attr_done = true;                                                                                              \
     }                                                                                                                \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
   } while (0)
@@ -1097,15 +1149,17 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   const size_t lds = res_bwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
   do {                                                                                                               \
-    auto kern = lstm_bwd_resident<T, HARD, NKV>;                                                                     \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
+    auto kern = g_res_mode.load(std::memory_order_relaxed) == 2 ? lstm_bwd_resident<T, HARD, NKV, true>               \
+                                                                : lstm_bwd_resident<T, HARD, NKV, false>;             \
+    static bool attr_set[2] = {false, false};                                                                        \
+    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2];                                     \
+    if (!attr_done) {                                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)res_bwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
         *err = check_launch("lstm resident attribute");                                                              \
         return true;                                                                                                 \
       }                                                                                                              \
-      attr_set = true;                                                                                               \
+      attr_done = true;                                                                                              \
     }                                                                                                                \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
   } while (0)
@@ -1233,7 +1287,23 @@ extern "C" int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uin
 // allow it (interleaved gates, B <= 32, one hidden size per call, slots x H/32 workgroups <= CUs).  Returns the
 // previous mode.
 extern "C" int caiman_lstm_resident_mode(int mode) {
-  return caiman::g_res_mode.exchange(mode ? 1 : 0);
+  return caiman::g_res_mode.exchange(mode == 2 ? 2 : (mode ? 1 : 0));
+}
+
+// Mode 2 = mode 1 with phase timers in workgroup 0 of slot 0: out[0..4] forward, out[5..9] backward, each
+// {wait for peers, operand row into LDS (+ MFMA stages, backward), MFMA + cell update / epilogue, drain + barrier}
+// in 10 ns ticks summed over timesteps, then the number of timesteps.  Clears the counters.
+extern "C" int caiman_lstm_resident_profile(uint32_t* out10) {
+  using namespace caiman;
+  int dev = 0;
+  if (!out10 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return CAIMAN_ERR_INVALID;
+  if (hipDeviceSynchronize() != hipSuccess) return check_launch("lstm resident profile");
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  for (int i = 0; i < 10; ++i) out10[i] = 0;
+  if (!g_res[dev].ok) return CAIMAN_OK;
+  volatile unsigned* f = g_res[dev].fail_host;
+  for (int i = 0; i < 5; ++i) { out10[i] = f[kResProfFwd + i]; out10[5 + i] = f[kResProfBwd + i]; f[kResProfFwd + i] = 0; f[kResProfBwd + i] = 0; }
+  return CAIMAN_OK;
 }
 
 // Wave calls served by a resident launch since the library was loaded (callers that account launches and bytes

@@ -188,6 +188,11 @@ int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base,
 int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
 int64_t caiman_lstm_resident_launches(void);
+/* Diagnostic: mode 2 = mode 1 plus phase timers in one workgroup (slot 0, first slice).  out10[0..4] forward and
+ * out[5..9] backward: 10 ns ticks spent {waiting for the peers' hand-off, bringing the operand row into LDS (backward:
+ * including the staged MFMAs), in the MFMA + cell update (backward: the epilogue), draining the stores + barrier},
+ * summed over timesteps, then the timestep count.  Synchronises the device and clears the counters. */
+int caiman_lstm_resident_profile(uint32_t* out10);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not

@@ -336,8 +336,6 @@ def test_resident_chunk_kernels_match_step_kernels(T, B, I, H, L, p, dtype):
     for i, (a, b) in enumerate(zip(res["res1"], res["step"])):
         scale = b.abs().max().item() + 1e-6
         assert torch.allclose(a, b, atol=(eps if i < 5 else 2e-2) * scale, rtol=0), (i, (a - b).abs().max().item() / scale)
-    if p > 0:
-        assert ((res["res1"][0] == 0) == (res["step"][0] == 0)).all()   # same dropout pattern
 
 
 def test_resident_kernels_under_uneven_load_and_fallbacks():

@@ -30,7 +30,7 @@ def run(m, x, h0, c0, w, mode, backward=True):
         (y.float() * w).sum().backward()
         out += [xin.grad.clone()] + [p.grad.clone() for p in m.parameters()]
     torch.cuda.synchronize()
-    lib.caiman_lstm_resident_mode(0)
+    lib.caiman_lstm_resident_mode(1)
     return out
 
 
@@ -82,7 +82,24 @@ def timing(T, B, I, H, L, reps):
             y.float().sum().backward()
         torch.cuda.synchronize()
         out[name + "_fwd_bwd_ms"] = (time.perf_counter() - t0) * 1e3 / reps
-    lib.caiman_lstm_resident_mode(0)
+    # phase timers of one workgroup (mode 2): where a timestep's time goes
+    import ctypes
+    lib.caiman_lstm_resident_mode(2)
+    buf = (ctypes.c_uint32 * 10)()
+    lib.caiman_lstm_resident_profile(buf)
+    for _ in range(reps):
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y, _, _ = m(xg, (h0, c0))
+        y.float().sum().backward()
+    lib.caiman_lstm_resident_profile(buf)
+    v = list(buf)
+    names = ("wait", "operand_to_lds", "mfma_cell", "drain_barrier")
+    for base, tag in ((0, "fwd"), (5, "bwd")):
+        n = max(v[base + 4], 1)
+        out[tag + "_us_per_timestep"] = {k: round(v[base + i] * 0.01 / n, 3) for i, k in enumerate(names)}
+        out[tag + "_timesteps"] = v[base + 4]
+    lib.caiman_lstm_resident_mode(1)
     out.update({"T": T, "B": B, "H": H, "L": L})
     return out
 
