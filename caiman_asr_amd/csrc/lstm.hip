@@ -782,19 +782,40 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
 // multiplying its half of a stage while the next one is in flight; the two K-halves meet in LDS and 256 threads
 // finish 4 units of one batch row each (32-byte dG pieces, written through for the next step's readers).
 // dC stays in registers across the launch.
+// DMA (H >= 256): the stages are 512 columns wide (1 KB per batch row = one `global_load_lds_dwordx4` wave
+// instruction) and go straight from L2 to a ring of NB LDS buffers, no staging registers: up to three stages
+// (96 KB per CU) are in flight instead of the 64 KB the register sets allow, which is what the per-CU rate of a
+// cross-XCD gather (about 1.3 us per round trip) asks for.
+template <int NKS>
+struct BwdResGeom {
+  static constexpr bool DMA = NKS >= 8;
+  static constexpr int H = NKS * 32;
+  static constexpr int NST = DMA ? NKS / 4 : 4;                 // stages per timestep
+  static constexpr int SW = 4 * H / NST;                        // columns per stage (512 with DMA)
+  static constexpr int LDW = SW + 8;
+  static constexpr int NB = DMA ? (NST < 4 ? NST : 4) : 2;      // LDS stage buffers
+  static constexpr int HK = 2 * NKS / NST;                      // k-steps per wave and stage (the two K-halves of a stage)
+};
+
 template <typename T, bool HARD, int NKS, bool PROF>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
-  // The dG row is streamed in NST stages of SW columns; two register sets keep two stages in flight, so the
-  // stream never drains between stages (with one set per stage the next loads left only after the LDS write).
-  constexpr int H = NKS * 32, NST = NKS >= 8 ? 8 : 4, SW = 4 * H / NST, LDW = SW + 8;
-  constexpr int HK = 2 * NKS / NST;          // k-steps per wave and stage (the two K-halves of a stage)
-  constexpr int PER = 32 * SW / 8 / 256;     // 16-byte pieces per thread and stage
-  static_assert(PER >= 1 && HK >= 1, "stage too narrow");
+  using G = BwdResGeom<NKS>;
+  // Without DMA the dG row is streamed in NST stages of SW columns through two register sets (two stages in flight).
+  constexpr bool DMA = G::DMA;
+  constexpr int H = G::H, NST = G::NST, SW = G::SW, LDW = G::LDW, NB = G::NB, HK = G::HK;
+  constexpr int PER = DMA ? 1 : 32 * SW / 8 / 256;     // 16-byte pieces per thread and stage (register path)
+  static_assert(PER >= 1 && HK >= 1 && (!DMA || SW == 512), "stage geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* buf = reinterpret_cast<T*>(smem);                                  // [2][32][LDW]
-  float* red = reinterpret_cast<float*>(buf + 2 * 32 * LDW);            // [kh 2][rt 2][ct 2][16 units][17]
+  // DMA: the ring buffers are four separate LDS objects so that the compiler's waitcnt pass can tell a read of one
+  // from a DMA still in flight to another (with one object it drains vmcnt to 0 before every LDS read); their total
+  // is a multiple of 16 bytes, so the dynamic region behind them (reduction scratch + flag) keeps its alignment.
+  __shared__ __attribute__((aligned(16))) T ring0[DMA ? 32 * LDW : 8], ring1[DMA ? 32 * LDW : 8], ring2[DMA ? 32 * LDW : 8],
+      ring3[DMA ? 32 * LDW : 8];
+  auto ring = [&](int k) -> T* { return k == 0 ? ring0 : (k == 1 ? ring1 : (k == 2 ? ring2 : ring3)); };
+  T* buf = reinterpret_cast<T*>(smem);                                  // register path: [2][32][LDW]
+  float* red = reinterpret_cast<float*>(buf + (DMA ? 0 : NB * 32 * LDW));   // [kh 2][rt 2][ct 2][16 units][17]
   int* flag = reinterpret_cast<int*>(red + 8 * 16 * 17);
 
   const int slot = blockIdx.y, j = blockIdx.x;
@@ -867,42 +888,86 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
       __syncthreads();
       if (*flag) break;
       CAIMAN_PROF_MARK(0)
-      const __amdgpu_buffer_rsrc_t rs = res_rsrc(dG + go);   // dG of the step before: row t+1, [B][4H]
-      frag v[2][PER];
+      if constexpr (DMA) {
+        // wave w brings rows w, w+4, .. of a stage: lane l the 16 bytes at column 8*l; a stage is 8 instructions per
+        // wave.  Written-through rows + sc1 on the load: the same hand-off as the register path, minus the registers.
+        const T* src = dG + go;
+        auto issue = [&](int q) {
+          const int pq = (q + rot) % NST;
+          T* bq = ring(q % NB);
 #pragma unroll
-      for (int q0 = 0; q0 < 2; ++q0)
+          for (int i = 0; i < 8; ++i) {
+            // always 8 instructions per wave and stage (the vmcnt arithmetic below counts them); batch rows past B
+            // re-read the last valid row: their columns of the product are never stored
+            const int b = wave + 4 * i, bs = b < B ? b : B - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (int64_t)bs * 4 * H + pq * SW + lane * 8),
+                (__attribute__((address_space(3))) void*)(bq + b * LDW), 16, 0, 16);
+          }
+        };
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-          const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
-          if (b < B) v[q0][i] = res_load16<T>(rs, (b * 4 * H + ((q0 + rot) % NST) * SW + k8 * 8) * (int)sizeof(T));
-          else {
+        for (int q = 0; q < NB; ++q) issue(q);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[q0][i][e] = static_cast<T>(0.f);
+        for (int q = 0; q < NST; ++q) {
+          // loads issued after stage q's: stages q+1 .. last; each is at most 8 instructions of this wave
+          constexpr int kNB = NB;
+          const int later = q == 0 ? kNB - 1 : ((NST - 1 - q) < (kNB - 2) ? (NST - 1 - q) : (kNB - 2));
+          // A bare s_barrier: __syncthreads() carries a workgroup release fence, which drains every DMA in flight.
+          // This wave's rows of stage q have landed (vmcnt) and its LDS reads of stage q-1 have returned (lgkmcnt)
+          // before it arrives; behind the barrier that holds for every wave.
+          if (later >= 3) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else if (later == 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else if (later == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (q >= 1 && q - 1 + NB < NST) issue(q - 1 + NB);
+          const T* bq = ring(q % NB);
+#pragma unroll
+          for (int i = 0; i < HK; ++i) {
+            const int kk = (kh * HK + i) * 32 + kq * 8;
+            const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDW + kk);
+            const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + kk);
+            acc[0] = mfma16(wreg[q][i], b0, acc[0]);
+            acc[1] = mfma16(wreg[q][i], b1, acc[1]);
           }
         }
-#pragma unroll
-      for (int q = 0; q < NST; ++q) {
-        T* bq = buf + (q & 1) * (32 * LDW);
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-          const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
-          *reinterpret_cast<frag*>(bq + b * LDW + k8 * 8) = v[q & 1][i];
-        }
-        if (q + 2 < NST) {
-#pragma unroll
+      } else {
+        const __amdgpu_buffer_rsrc_t rs = res_rsrc(dG + go);   // dG of the step before: row t+1, [B][4H]
+        frag v[2][PER];
+  #pragma unroll
+        for (int q0 = 0; q0 < 2; ++q0)
+  #pragma unroll
           for (int i = 0; i < PER; ++i) {
             const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
-            if (b < B) v[q & 1][i] = res_load16<T>(rs, (b * 4 * H + ((q + 2 + rot) % NST) * SW + k8 * 8) * (int)sizeof(T));
+            if (b < B) v[q0][i] = res_load16<T>(rs, (b * 4 * H + ((q0 + rot) % NST) * SW + k8 * 8) * (int)sizeof(T));
+            else {
+  #pragma unroll
+              for (int e = 0; e < 8; ++e) v[q0][i][e] = static_cast<T>(0.f);
+            }
           }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < HK; ++i) {
-          const int kk = (kh * HK + i) * 32 + kq * 8;
-          const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDW + kk);
-          const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + kk);
-          acc[0] = mfma16(wreg[q][i], b0, acc[0]);
-          acc[1] = mfma16(wreg[q][i], b1, acc[1]);
+  #pragma unroll
+        for (int q = 0; q < NST; ++q) {
+          T* bq = buf + (q & 1) * (32 * LDW);
+  #pragma unroll
+          for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
+            *reinterpret_cast<frag*>(bq + b * LDW + k8 * 8) = v[q & 1][i];
+          }
+          if (q + 2 < NST) {
+  #pragma unroll
+            for (int i = 0; i < PER; ++i) {
+              const int idx = tid + 256 * i, b = idx / (SW / 8), k8 = idx % (SW / 8);
+              if (b < B) v[q & 1][i] = res_load16<T>(rs, (b * 4 * H + ((q + 2 + rot) % NST) * SW + k8 * 8) * (int)sizeof(T));
+            }
+          }
+          __syncthreads();
+  #pragma unroll
+          for (int i = 0; i < HK; ++i) {
+            const int kk = (kh * HK + i) * 32 + kq * 8;
+            const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDW + kk);
+            const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + kk);
+            acc[0] = mfma16(wreg[q][i], b0, acc[0]);
+            acc[1] = mfma16(wreg[q][i], b1, acc[1]);
+          }
         }
       }
     }
@@ -1123,9 +1188,12 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
 }
 
 template <typename T>
-inline size_t res_bwd_lds(int H) {
-  const int nst = H / 32 >= 8 ? 8 : 4;   // as in lstm_bwd_resident
-  return (size_t)(2 * 32 * (4 * H / nst + 8)) * sizeof(T) + (size_t)8 * 16 * 17 * sizeof(float) + 16;
+inline size_t res_bwd_lds(int H) {   // BwdResGeom
+  const int nks = H / 32;
+  const bool dma = nks >= 8;
+  const int nst = dma ? nks / 4 : 4, nb = dma ? (nst < 4 ? nst : 4) : 2;
+  // dynamic part only: with DMA the ring buffers are static LDS objects of the kernel
+  return (dma ? 0 : (size_t)(nb * 32 * (4 * H / nst + 8)) * sizeof(T)) + (size_t)8 * 16 * 17 * sizeof(float) + 16;
 }
 
 template <typename T, bool HARD>

@@ -79,10 +79,21 @@ def test_mfma_lstm_state_passing_and_schedule_invariance_at_base_width():
         b, (hb, cb), _ = m(x[33:], sa)
         m.pipeline_layers = False
         ref, (hr, cr), _ = m(x)
+        from caiman_asr_amd import _lib
+        prev = _lib.lib().caiman_lstm_resident_mode(0)
+        try:
+            m.pipeline_layers = True
+            full0, (hf0, cf0), _ = m(x)
+        finally:
+            _lib.lib().caiman_lstm_resident_mode(prev)
     # concat(A, B) == A then B | state  (training/tests/rnnt/test_model.py:107-296); the carried state is
     # rounded to the input dtype (fp32 here) exactly like the hand-over inside one call is rounded to bf16
     assert torch.allclose(torch.cat([a, b]).float(), full.float(), atol=2e-2)
     assert torch.allclose(hb.float(), hf.float(), atol=2e-2) and torch.allclose(cb.float(), cf.float(), atol=4e-2)
-    # the layer pipeline only re-orders launches: bit-identical to the layer-by-layer schedule
-    assert torch.equal(ref, full) and torch.equal(hr, hf) and torch.equal(cr, cf)
+    # the layer pipeline only re-orders launches: with the per-timestep kernels on both sides it is bit-identical to
+    # the layer-by-layer schedule; the weight-resident chunk kernels (default) sum the recurrent product in another
+    # order and use the hardware exp / rcp: equal to the storage type's resolution
+    assert torch.equal(ref, full0) and torch.equal(hr, hf0) and torch.equal(cr, cf0)
+    assert torch.allclose(ref.float(), full.float(), atol=1e-2 * ref.float().abs().max().item())
+    assert torch.allclose(cr.float(), cf.float(), atol=1e-2 * cr.float().abs().max().item())
     assert ah.shape == (L, T, B, H) and torch.equal(ah[-1], full)
