@@ -541,7 +541,11 @@ struct FastAct<false> : Act<float, false> {
 // as the step kernel's round trip through memory does).
 // Every spin is bounded by a wall-clock limit; a timeout raises `fail` (host-visible) and the workgroup leaves.
 // ===========================================================================
-constexpr int kResTimeoutTicks = 5000000;   // wall_clock64 runs at 100 MHz: 50 ms
+// wall_clock64 runs at 100 MHz: 5 s.  A hand-off normally takes microseconds, but a workgroup that has not been placed
+// yet (a collective's kernel of another stream holds its CU: neither kernel can share a CU with a resident workgroup,
+// whose four waves fill the register file) keeps its peers waiting for as long as that kernel runs, and a
+// collective waits for the slowest rank.
+constexpr int kResTimeoutTicks = 500000000;
 constexpr int kResCounterStride = 32;       // one 128-byte line per slot counter
 
 __device__ __forceinline__ bool res_wait(unsigned* cnt, unsigned target, unsigned* fail_dev, unsigned* fail_host) {
