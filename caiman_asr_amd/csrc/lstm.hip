@@ -1096,6 +1096,7 @@ struct ResState {
   unsigned* fail_host = nullptr;
   int next = 0;
   int cus = 0;
+  int dev = 0;
   bool ok = false;
   // Two resident grids on different streams could each hold part of the chip and wait for the rest: a resident
   // launch on another stream than the previous one first waits for that one's completion event.
@@ -1133,6 +1134,7 @@ ResState* res_state() {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
     st.cus = prop.multiProcessorCount;
+    st.dev = dev;
     if (hipHostMalloc(reinterpret_cast<void**>(&st.fail_host), 64, hipHostMallocMapped) != hipSuccess) return nullptr;
     for (int i = 0; i < 16; ++i) st.fail_host[i] = 0;
     for (int i = 0; i < kResPool; ++i)
@@ -1165,8 +1167,8 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   do {                                                                                                               \
     auto kern = g_res_mode.load(std::memory_order_relaxed) == 2 ? lstm_fwd_resident<T, HARD, NKV, true>               \
                                                                 : lstm_fwd_resident<T, HARD, NKV, false>;             \
-    static bool attr_set[2] = {false, false};                                                                        \
-    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2];                                     \
+    static bool attr_set[2][16] = {};   /* per device: the attribute belongs to the device's code object */         \
+    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2][st->dev];                            \
     if (!attr_done) {                                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)res_fwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
@@ -1223,8 +1225,8 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   do {                                                                                                               \
     auto kern = g_res_mode.load(std::memory_order_relaxed) == 2 ? lstm_bwd_resident<T, HARD, NKV, true>               \
                                                                 : lstm_bwd_resident<T, HARD, NKV, false>;             \
-    static bool attr_set[2] = {false, false};                                                                        \
-    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2];                                     \
+    static bool attr_set[2][16] = {};   /* per device: the attribute belongs to the device's code object */         \
+    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2][st->dev];                            \
     if (!attr_done) {                                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)res_bwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
