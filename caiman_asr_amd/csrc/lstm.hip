@@ -702,14 +702,44 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LDS reads run a batch of KB k-steps ahead of the MFMAs that consume them: left to itself the compiler, short
+    // of registers, put one read and a full wait in front of every pair of MFMAs (2.7 us of exposed LDS latency per
+    // timestep).  The empty asm pins the order: the next batch's reads are issued before this batch's MFMAs.
+    {
+      constexpr int KB = (NKS % 4 == 0) ? 4 : 2, NB_ = NKS / KB;
+      frag bb[2][KB][2];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const frag b0 = *reinterpret_cast<const frag*>(hs + r * LDH + ks * 32 + kq * 8);
-      const frag b1 = *reinterpret_cast<const frag*>(hs + (16 + r) * LDH + ks * 32 + kq * 8);
-      acc[0][0] = mfma16(wreg[0][ks], b0, acc[0][0]);
-      acc[0][1] = mfma16(wreg[0][ks], b1, acc[0][1]);
-      acc[1][0] = mfma16(wreg[1][ks], b0, acc[1][0]);
-      acc[1][1] = mfma16(wreg[1][ks], b1, acc[1][1]);
+      for (int i = 0; i < KB; ++i) {
+        bb[0][i][0] = *reinterpret_cast<const frag*>(hs + r * LDH + i * 32 + kq * 8);
+        bb[0][i][1] = *reinterpret_cast<const frag*>(hs + (16 + r) * LDH + i * 32 + kq * 8);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB_; ++nb) {
+        if (nb + 1 < NB_) {
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (nb + 1) * KB + i;
+            bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(hs + r * LDH + ks * 32 + kq * 8);
+            bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(hs + (16 + r) * LDH + ks * 32 + kq * 8);
+          }
+        }
+        // the MFMAs below take their operands from this asm, so they cannot be hoisted back above the reads just issued
+        if constexpr (KB == 4)
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                       :: "memory");
+        else
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1])
+                       :: "memory");
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const int ks = nb * KB + i;
+          acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+          acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+          acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+          acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+        }
+      }
     }
     // cell update, lane-local: acc register q = gate q of (unit kq of the row tile, batch row r of the column tile)
 #pragma unroll
@@ -911,9 +941,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
         };
 #pragma unroll
         for (int q = 0; q < NB; ++q) issue(q);
+        static_assert(HK == 8, "DMA stages are 16 k-steps wide");
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
-          // loads issued after stage q's: stages q+1 .. last; each is at most 8 instructions of this wave
+          // loads issued after stage q's: stages q+1 .. last; each is exactly 8 instructions of this wave
           constexpr int kNB = NB;
           const int later = q == 0 ? kNB - 1 : ((NST - 1 - q) < (kNB - 2) ? (NST - 1 - q) : (kNB - 2));
           // A bare s_barrier: __syncthreads() carries a workgroup release fence, which drains every DMA in flight.
@@ -925,13 +956,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
           if (q >= 1 && q - 1 + NB < NST) issue(q - 1 + NB);
           const T* bq = ring(q % NB);
+          // all of the stage's fragments in flight before the first MFMA; the MFMAs take their operands from the asm,
+          // so they cannot be hoisted back between the reads (see the forward kernel).  Pipelining the reads of stage q
+          // under the MFMAs of stage q-1 as well changed nothing: the stage time is the DMA stream's.
+          frag bb[HK][2];
 #pragma unroll
           for (int i = 0; i < HK; ++i) {
             const int kk = (kh * HK + i) * 32 + kq * 8;
-            const frag b0 = *reinterpret_cast<const frag*>(bq + r * LDW + kk);
-            const frag b1 = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + kk);
-            acc[0] = mfma16(wreg[q][i], b0, acc[0]);
-            acc[1] = mfma16(wreg[q][i], b1, acc[1]);
+            bb[i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + kk);
+            bb[i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + kk);
+          }
+          asm volatile("" : "+v"(bb[0][0]), "+v"(bb[0][1]), "+v"(bb[1][0]), "+v"(bb[1][1]), "+v"(bb[2][0]), "+v"(bb[2][1]),
+                            "+v"(bb[3][0]), "+v"(bb[3][1]), "+v"(bb[4][0]), "+v"(bb[4][1]), "+v"(bb[5][0]), "+v"(bb[5][1]),
+                            "+v"(bb[6][0]), "+v"(bb[6][1]), "+v"(bb[7][0]), "+v"(bb[7][1])
+                       :: "memory");
+#pragma unroll
+          for (int i = 0; i < HK; ++i) {
+            acc[0] = mfma16(wreg[q][i], bb[i][0], acc[0]);
+            acc[1] = mfma16(wreg[q][i], bb[i][1], acc[1]);
           }
         }
       } else {
