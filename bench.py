@@ -334,15 +334,15 @@ def main():
                                    "note": ("avg_launch_us is event-to-event over sampled brackets (kernel + its counter memset + "
                                             "the events' own cost); the kernel alone is `rocprof_kernel_avg_us` (profiles/). "
                                             "The resident kernel is bounded by its chain of dependent timesteps (hand-off of "
-                                            "the dG row between the workgroups of a layer), not by HBM: DESIGN.md section 3")}
+                                            "the dG row between the workgroups of a layer), not by HBM: DESIGN.md section 4")}
                 try:   # the committed rocprofv3 --kernel-trace --stats summary of this command
                     import csv
 
                     with open(os.path.join(ROOT, "profiles", "r01_bench_v13_kernel_stats.csv")) as f:
-                        for row in csv.DictReader(f):
-                            if kname in row["Name"] and ("Li32E" in row["Name"] if resident else "Li8E" in row["Name"]):
-                                out["roofline"]["rocprof_kernel_avg_us"] = float(row["AverageNs"]) / 1e3
-                                break
+                        hits = [(int(row["Calls"]), float(row["TotalDurationNs"])) for row in csv.DictReader(f) if kname in row["Name"]]
+                    # every instantiation of the kernel (encoder H = 1024 and the prediction network's narrower launches),
+                    # as the live bracket sees them
+                    out["roofline"]["rocprof_kernel_avg_us"] = sum(t for _, t in hits) / sum(c for c, _ in hits) / 1e3
                 except Exception:
                     pass
             if "loss_bwd" in summ:
