@@ -83,7 +83,7 @@ class BwdSlot(ctypes.Structure):
                 ("dG", ctypes.c_void_p), ("ring", ctypes.c_void_p), ("dC", ctypes.c_void_p),
                 ("parity", ctypes.c_int32), ("nsteps", ctypes.c_int32), ("has_next", ctypes.c_int32),
                 ("drop_p", ctypes.c_float), ("drop_counter", ctypes.c_uint64), ("hidden", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("dbias", ctypes.c_void_p)]
 
 class BeamConfig(ctypes.Structure):
     """caiman_beam_config_t (include/caiman_beam.h)."""

@@ -254,6 +254,7 @@ struct BwdSlots {
   uint64_t drop_base[kMaxSlots];
   float drop_p[kMaxSlots];
   int hidden[kMaxSlots];  // as in FwdSlots
+  float* dbias[kMaxSlots];  // NULL, or fp32 [4H] (interleaved layout): += sum over the call's dG rows
   uint64_t seed;
 };
 
@@ -884,6 +885,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   const bool ep = eb < B;
   const int64_t eoff = (int64_t)eb * H + u;
   float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[4][4];   // bias gradient: this thread's batch row, units u..u+3 x gates, summed over the launch's timesteps
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[q][e] = 0.f;
   if (ep) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoff);
 #pragma unroll
@@ -1047,6 +1053,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
         vG[q] = static_cast<T>(dc * gi * FastAct<HARD>::tanh_prime(gg));
         vO[q] = static_cast<T>(dy * ct * FastAct<HARD>::sigm_prime(go_));
         dcs[q] = dc * gf;
+        bsum[q][0] += static_cast<float>(vI[q]); bsum[q][1] += static_cast<float>(vF[q]);
+        bsum[q][2] += static_cast<float>(vG[q]); bsum[q][3] += static_cast<float>(vO[q]);
       }
       frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
       o0[0] = vI[0]; o0[1] = vF[0]; o0[2] = vG[0]; o0[3] = vO[0]; o0[4] = vI[1]; o0[5] = vF[1]; o0[6] = vG[1]; o0[7] = vO[1];
@@ -1070,6 +1078,34 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CAIMAN_PROF_MARK(3)
+  }
+  if (w.dbias[slot] && !*flag) {
+    // sum over the 32 batch rows: lanes 8 apart hold the same units (rows wave*8 + lane/8), then the four waves meet
+    // in LDS; this workgroup is the only writer of its 128 entries in this launch, launches are stream-ordered
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bsum[q][e];
+        v += __shfl_xor(v, 8, kWave);
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        bsum[q][e] = v;
+      }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave * 8 + lane) * 16 + q * 4 + e] = bsum[q][e];
+    }
+    __syncthreads();
+    if (tid < 128) {   // entry tid = (unit within the 32, gate): column group tid / 16, element tid % 16
+      const int cg = tid >> 4, el = tid & 15;
+      const float v = red[(0 * 8 + cg) * 16 + el] + red[(1 * 8 + cg) * 16 + el] + red[(2 * 8 + cg) * 16 + el] +
+                      red[(3 * 8 + cg) * 16 + el];
+      w.dbias[slot][(int64_t)(j * 32) * 4 + tid] += v;
+    }
   }
   if (prof) {
     for (int i = 0; i < 4; ++i)
@@ -1111,6 +1147,21 @@ int launch_fwd_waves(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t 
   return check_launch("lstm forward wave");
 }
 
+// dbias[c] += sum over the call's n*B dG rows (per-timestep path: the step kernels do not carry the sums).  The rows
+// of a backward call run DOWN from dG_hi; one thread per column, neighbours read neighbouring columns.
+template <typename T>
+__global__ __launch_bounds__(256) void dbias_rows_kernel(const T* __restrict__ dG_hi, int64_t row_elems, int n_rows_t, int B,
+                                                        int cols, float* __restrict__ dbias) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int t = 0; t < n_rows_t; ++t) {
+    const T* p = dG_hi - (int64_t)t * row_elems + c;
+    for (int b = 0; b < B; ++b) s += static_cast<float>(p[(int64_t)b * cols]);
+  }
+  dbias[c] += s;
+}
+
 template <typename T, bool HARD, bool IL>
 int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s) {
   const int nkw = (int)(((4 * H >> 5) + 15) / 16);
@@ -1126,6 +1177,12 @@ int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t 
       default: CAIMAN_BWD(0); break;
     }
 #undef CAIMAN_BWD
+  }
+  for (int i = 0; i < n_slots; ++i) {
+    if (!w.dbias[i] || w.nsteps[i] <= 0) continue;
+    const int Hs = w.hidden[i] ? w.hidden[i] : (int)H;
+    hipLaunchKernelGGL((dbias_rows_kernel<T>), dim3((unsigned)((4 * Hs + 255) / 256)), dim3(256), 0, s, w.dG[i],
+                       (int64_t)B * 4 * Hs, w.nsteps[i], (int)B, 4 * Hs, w.dbias[i]);
   }
   return check_launch("lstm backward wave");
 }
@@ -1522,6 +1579,8 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
       CAIMAN_CHECK(slots[i].hidden == 0 || (slots[i].hidden >= 32 && slots[i].hidden % 32 == 0 && slots[i].hidden <= H),
                    "lstm_wave_bwd: slot %d hidden size must be 0 or a multiple of 32 not above H", i);
       w.hidden[i] = slots[i].hidden;
+      CAIMAN_CHECK(slots[i].dbias == nullptr || gate_layout != 0, "lstm_wave_bwd: dbias needs the interleaved gate layout");
+      w.dbias[i] = slots[i].dbias;
     }
     w.seed = seed;
     if (gate_layout) {

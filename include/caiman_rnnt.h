@@ -161,6 +161,11 @@ typedef struct {
   int32_t parity; int32_t nsteps; int32_t has_next; float drop_p;
   uint64_t drop_counter;
   int32_t hidden; int32_t reserved; /* hidden: as in the forward slot */
+  float* dbias; /* NULL, or fp32 [4H] in the call's gate layout: the call ADDS the sum of the dG rows it produces for this
+                   slot over its timesteps and batch rows -- the bias gradient of the layer (reference:
+                   training/lib/src/rnnt_ext/custom_lstm/lstm.py:57, `dB = dG.sum([0, 1])`, a separate pass over dG).
+                   The resident kernel keeps the sums in registers; the per-timestep path adds them with one extra
+                   reduction launch per call.  Interleaved gate layout only. */
 } caiman_lstm_bwd_slot_t;
 /* gate_layout: 0 = the reference's gates / dG layout [B, 4, H] (gate-major, lstm.cu:99-102);
  *              1 = interleaved [B, H, 4] (the 4 gates of a hidden unit adjacent): an internal layout of the
