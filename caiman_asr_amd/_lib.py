@@ -122,6 +122,7 @@ _SIGS = {
     "caiman_lstm_resident_mode": ([I32], ctypes.c_int),
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
     "caiman_lstm_resident_launches": ([], ctypes.c_int64),
+    "caiman_lstm_resident_would_run": ([I64, I64, I32], ctypes.c_int),
     "caiman_lstm_resident_profile": ([P], ctypes.c_int),
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),

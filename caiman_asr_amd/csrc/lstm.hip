@@ -1148,18 +1148,36 @@ int launch_fwd_waves(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t 
 }
 
 // dbias[c] += sum over the call's n*B dG rows (per-timestep path: the step kernels do not carry the sums).  The rows
-// of a backward call run DOWN from dG_hi; one thread per column, neighbours read neighbouring columns.
+// of a backward call run DOWN from dG_hi.  A workgroup owns 64 columns; its four waves take every fourth row (eight
+// loads in flight each) and meet in LDS, so the result has a fixed summation order.
 template <typename T>
 __global__ __launch_bounds__(256) void dbias_rows_kernel(const T* __restrict__ dG_hi, int64_t row_elems, int n_rows_t, int B,
                                                         int cols, float* __restrict__ dbias) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int total = n_rows_t * B;
   float s = 0.f;
-  for (int t = 0; t < n_rows_t; ++t) {
-    const T* p = dG_hi - (int64_t)t * row_elems + c;
-    for (int b = 0; b < B; ++b) s += static_cast<float>(p[(int64_t)b * cols]);
+  if (c < cols) {
+    int r = grp;
+    for (; r + 28 < total; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = r + 4 * i, t = rr / B, b = rr - t * B;
+        v[i] = static_cast<float>(dG_hi[-(int64_t)t * row_elems + (int64_t)b * cols + c]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; r < total; r += 4) {
+      const int t = r / B, b = r - t * B;
+      s += static_cast<float>(dG_hi[-(int64_t)t * row_elems + (int64_t)b * cols + c]);
+    }
   }
-  dbias[c] += s;
+  part[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < cols) dbias[c] += part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
 }
 
 template <typename T, bool HARD, bool IL>
@@ -1181,7 +1199,7 @@ int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t 
   for (int i = 0; i < n_slots; ++i) {
     if (!w.dbias[i] || w.nsteps[i] <= 0) continue;
     const int Hs = w.hidden[i] ? w.hidden[i] : (int)H;
-    hipLaunchKernelGGL((dbias_rows_kernel<T>), dim3((unsigned)((4 * Hs + 255) / 256)), dim3(256), 0, s, w.dG[i],
+    hipLaunchKernelGGL((dbias_rows_kernel<T>), dim3((unsigned)((4 * Hs + 63) / 64)), dim3(256), 0, s, w.dG[i],
                        (int64_t)B * 4 * Hs, w.nsteps[i], (int)B, 4 * Hs, w.dbias[i]);
   }
   return check_launch("lstm backward wave");
@@ -1477,6 +1495,18 @@ extern "C" int caiman_lstm_resident_profile(uint32_t* out10) {
   volatile unsigned* f = g_res[dev].fail_host;
   for (int i = 0; i < 5; ++i) { out10[i] = f[kResProfFwd + i]; out10[5 + i] = f[kResProfBwd + i]; f[kResProfFwd + i] = 0; f[kResProfBwd + i] = 0; }
   return CAIMAN_OK;
+}
+
+// 1 when a wave call of this shape (interleaved gates, n_slots slots of hidden size H, several timesteps) would be
+// served by a resident launch on the current device.  Callers use it to decide whether to ask for the fused bias
+// gradients (`dbias`): the per-timestep path fills them too, but with an extra reduction launch per call.
+extern "C" int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots) {
+  using namespace caiman;
+  if (!g_res_mode.load(std::memory_order_relaxed) || B < 1 || B > 32 || H % 32 != 0 || n_slots < 1 || n_slots > kMaxSlots) return 0;
+  const int nks = (int)(H / 32);
+  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return 0;
+  ResState* st = res_state();
+  return (st && (int64_t)n_slots * nks <= st->cus) ? 1 : 0;
 }
 
 // Wave calls served by a resident launch since the library was loaded (callers that account launches and bytes

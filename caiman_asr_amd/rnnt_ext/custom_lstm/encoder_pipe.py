@@ -291,7 +291,10 @@ class EncoderPipeFunction(torch.autograd.Function):
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), True) if h else 0 for h in Hl]
         # bias gradients: the backward kernels add each launch's dG row sums here (BwdSlot.dbias), no pass over dG afterwards
-        dbias = torch.zeros((L, 4 * max(Hl)), dtype=torch.float32, device=dev)
+        # (only where the weight-resident kernels run: they keep the sums in registers; the per-timestep path would need an
+        # extra reduction launch per call, slower than one batched sum at the end)
+        fused_db = all(lib.caiman_lstm_resident_would_run(B, h, min(8, L)) for h in set(Hl))
+        dbias = torch.zeros((L, 4 * max(Hl)), dtype=torch.float32, device=dev) if fused_db else None
         boundary_done = set()   # post chunks whose input gradient has been un-stacked into delta[La-1]
         W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]).transpose(1, 2) if (BMM and Lb > 2) else None   # views [Lb-1, 4H, H]
         for tick in reversed(_schedule(nA, nB, La, Lb, f, nP, Lp)):
@@ -323,7 +326,7 @@ class EncoderPipeFunction(torch.autograd.Function):
                 slots.append(_lib.BwdSlot(wt[l].data_ptr(), G[l][thi].data_ptr(), C[l][thi].data_ptr(), d[thi].data_ptr(),
                                           d.stride(0), d.stride(1), dG[l][thi].data_ptr(), ring[l].data_ptr(),
                                           dC[l].data_ptr(), thi & 1, n, int(thi < Tl[l] - 1), p_slot, base[l] + thi * row,
-                                          hl if hl != H else 0, 0, dbias[l].data_ptr()))
+                                          hl if hl != H else 0, 0, dbias[l].data_ptr() if fused_db else None))
                 nbytes += n * sbytes[l]
             arr = (_lib.BwdSlot * len(slots))(*slots)
             n_launch = max(s_.nsteps for s_ in slots)
@@ -376,24 +379,25 @@ class EncoderPipeFunction(torch.autograd.Function):
 
         # post layers have identical shapes: their recurrent-weight gradients (all Lb), their input-weight gradients
         # (layers 1..Lb-1) and all bias gradients are three batched calls instead of 3 * Lb
-        post_R = post_W = None
+        post_R = post_W = post_b = None
         if BMM and Lb > 1:
             dgb = dGb.view(Lb, T2 * B, 4 * H)
             post_R = torch.bmm(dgb.transpose(1, 2), Yb[:, :T2].reshape(Lb, T2 * B, H))
             xin = (YMb[:Lb - 1] if pl[La] > 0.0 else Yb[:Lb - 1, 1:]).reshape(Lb - 1, T2 * B, H)
             post_W = torch.bmm(dgb[1:].transpose(1, 2), xin)
+            post_b = None if fused_db else dgb.sum(1)
         per_layer = [None] * L
         for l in (reversed(range(L)) if direct else range(L)):
             T, hl = Tl[l], Hl[l]
             dg = dG[l].reshape(T * B, 4 * hl)
             m = l - La
             if post_R is not None and 0 <= m < Lb:
-                dB = dbias[l, :4 * hl]
+                dB = dbias[l, :4 * hl] if fused_db else post_b[m]
                 gW = post_W[m - 1] if m >= 1 else torch.matmul(dg.t(), layer_input(l))
                 g4 = [gW, post_R[m], dB, dB]
             else:
                 yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
-                dB = dbias[l, :4 * hl]
+                dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)
                 g4 = [torch.matmul(dg.t(), layer_input(l)), torch.matmul(dg.t(), yprev), dB, dB]
             if direct:
                 for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], g4):

@@ -204,7 +204,10 @@ class StackFunction(torch.autograd.Function):
         wt = _Scratch.get("bw", L * 4 * H * H, dt, dev).view(L, -1)
         ring = _Scratch.get("br", L * 2 * bp * 4 * H, dt, dev).view(L, -1)
         dC = _Scratch.get("bc", L * B * H, torch.float32, dev).view(L, -1)
-        dbias = torch.zeros((L, 4 * H), dtype=torch.float32, device=dev)   # filled by the backward kernels (BwdSlot.dbias)
+        # bias gradients from the backward kernels (BwdSlot.dbias) where the weight-resident kernels run; otherwise one
+        # reduction per layer at the end (cheaper than the per-timestep path's extra launch per call)
+        fused_db = bool(lib.caiman_lstm_resident_would_run(B, H, min(8, L)))
+        dbias = torch.zeros((L, 4 * H), dtype=torch.float32, device=dev) if fused_db else None
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
                                                 B, H, tag, 1, INTERLEAVED, st))
@@ -240,7 +243,7 @@ class StackFunction(torch.autograd.Function):
                 slots.append(_lib.BwdSlot(wt[l].data_ptr(), G[l, thi].data_ptr(), Cs[l, thi].data_ptr(),
                                           d[thi].data_ptr(), d.stride(0), d.stride(1), dG[l, thi].data_ptr(),
                                           ring[l].data_ptr(), dC[l].data_ptr(), thi & 1, n, int(thi < T - 1),
-                                          p_slot, (l * T + thi) * row, 0, 0, dbias[l].data_ptr()))
+                                          p_slot, (l * T + thi) * row, 0, 0, dbias[l].data_ptr() if fused_db else None))
             arr = (_lib.BwdSlot * len(slots))(*slots)
             n_launch = max(s_.nsteps for s_ in slots)
             with _lib.timed("lstm_bwd", n_launch, sb * sum(s_.nsteps for s_ in slots)) as tm:
@@ -257,7 +260,7 @@ class StackFunction(torch.autograd.Function):
                 xin = x.detach().flatten(0, 1).to(dt)
             else:
                 xin = (YM[l - 1] if drop > 0.0 else Y[l - 1, 1:]).reshape(T * B, H)
-            dB = _unperm_rows(dbias[l], H)
+            dB = _unperm_rows(dbias[l] if fused_db else dg.sum(0), H)
             return [_unperm_rows(torch.matmul(dg.t(), xin), H),
                     _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
 

@@ -193,6 +193,9 @@ int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base,
 int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
 int64_t caiman_lstm_resident_launches(void);
+/* 1 when a multi-timestep wave call with n_slots slots of hidden size H and batch B would be one resident launch on
+ * the current device (mode on, B <= 32, H/32 in {2,4,8,16,24,32}, n_slots * H/32 <= CUs). */
+int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots);
 /* Diagnostic: mode 2 = mode 1 plus phase timers in one workgroup (slot 0, first slice).  out10[0..4] forward and
  * out[5..9] backward: 10 ns ticks spent {waiting for the peers' hand-off, bringing the operand row into LDS (backward:
  * including the staged MFMAs), in the MFMA + cell update (backward: the epilogue), draining the stores + barrier},

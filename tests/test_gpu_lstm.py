@@ -370,3 +370,27 @@ def test_resident_kernels_under_uneven_load_and_fallbacks():
     _, n = _run_stack(m, xb, torch.zeros(L, 40, H, device=DEV), torch.zeros(L, 40, H, device=DEV),
                       torch.randn(T, 40, H, device=DEV), torch.bfloat16, 1)
     assert n == 0
+
+
+def test_fused_bias_gradient_on_the_per_timestep_path(monkeypatch):
+    """BwdSlot.dbias (include/caiman_rnnt.h) must hold the layer's bias gradient whichever kernels served the call.
+    The Python side only asks for it where the resident kernels run; force the request while the per-timestep
+    kernels are selected, so that the extra reduction launch of that path is compared with `dG.sum` too."""
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    T, B, I, H, L = 45, 9, 32, 128, 3
+    torch.manual_seed(21)
+    m = CustomLSTM(I, H, L, device=DEV)
+    x = torch.randn(T, B, I, device=DEV)
+    h0 = torch.zeros(L, B, H, device=DEV)
+    c0 = torch.zeros(L, B, H, device=DEV)
+    w = torch.randn(T, B, H, device=DEV)
+    ref, n = _run_stack(m, x, h0, c0, w, torch.bfloat16, 0)
+    assert n == 0
+    lib = _lib.lib()
+    monkeypatch.setattr(lib, "caiman_lstm_resident_would_run", lambda *a: 1, raising=False)
+    got, n = _run_stack(m, x, h0, c0, w, torch.bfloat16, 0)
+    assert n == 0
+    for a, b in zip(got, ref):
+        assert torch.allclose(a, b, atol=1e-2 * (b.abs().max().item() + 1e-6), rtol=0)
