@@ -352,6 +352,9 @@ def main():
                                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                             "avg_launch_ms": ms / n_launch, "launches": n_launch}
+        native = _lib.lib()
+        out["lstm_resident"] = {"launches": int(native.caiman_lstm_resident_launches()),
+                                "handoff_timeouts": int(native.caiman_lstm_resident_failures())}   # must be 0
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # the box exposes more logical CPUs than this job's share (16 per GPU): oversubscribing
