@@ -244,6 +244,7 @@ class EncoderPipeFunction(torch.autograd.Function):
         from caiman_asr_amd.train_utils import overlap
 
         overlap.flush_deferred()
+        overlap.fence_collectives()   # resident launches and a collective's kernel must not be placed by halves together
         saved = list(ctx.saved_tensors)
         x, Ga, Gb, Ya, Yb, Ca, Cb = saved[:7]
         Wp, Rp = saved[7:7 + L], saved[7 + L:7 + 2 * L]

@@ -58,6 +58,7 @@ class FlatGradReducer:
 
             self._overlap = overlap
             overlap.register_grad_ready_callback(self._on_grad)
+            overlap.register_comm_stream(self.comm_stream)   # LSTM stacks fence against it (overlap.fence_collectives)
 
     # ---- per-step protocol: backward() ... finish() ---------------------------------------
     def _on_grad(self, p):

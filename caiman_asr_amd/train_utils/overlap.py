@@ -30,6 +30,27 @@ def side_streams():
     return list(_side.values())
 
 
+_comm_streams = []   # streams on which gradient collectives run (train_utils/distributed.py registers its own)
+
+
+def register_comm_stream(stream):
+    if stream is not None and stream not in _comm_streams:
+        _comm_streams.append(stream)
+
+
+def fence_collectives():
+    """Called at the start of an LSTM stack's backward pass: the weight-resident LSTM kernels want every CU of the
+    chip (a resident workgroup fills its CU's register file), a collective's kernel holds some for as long as the
+    slowest rank takes, and two kernels that are each placed by halves could wait for each other across ranks
+    (DESIGN.md section 5).  So the stack's launches start only after the collectives queued so far are done; the
+    collectives launched afterwards overlap ordinary kernels (weight-gradient GEMMs), as before."""
+    if not _comm_streams:
+        return
+    cur = torch.cuda.current_stream()
+    for s in _comm_streams:
+        cur.wait_stream(s)
+
+
 def side_stream(device) -> torch.cuda.Stream:
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _side:
