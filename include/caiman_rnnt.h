@@ -44,7 +44,8 @@ enum {
 
 typedef void* caiman_stream_t; /* hipStream_t */
 
-/* Library identity / diagnostics. */
+/* Library identity / diagnostics.  ABI version 3: slot structs of the wave calls carry `hidden` (2) and the backward
+ * slot `dbias` (3); the resident-kernel controls were added with 3. */
 int caiman_abi_version(void);
 const char* caiman_last_error(void);
 /* 1 when the library was built with device code for gfx950. */
