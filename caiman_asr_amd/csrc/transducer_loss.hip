@@ -329,7 +329,15 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
       const int64_t c = c0 + (int64_t)k * kWave;
-      if (c < nfull) v[k] = *reinterpret_cast<const Vt*>(rx + c * VEC);
+      if (c < nfull) {
+        if constexpr (sizeof(Vt) == 16) {   // streamed once: keep it out of the caches' way
+          using u4 = __attribute__((ext_vector_type(4))) unsigned;
+          const u4 raw = __builtin_nontemporal_load(reinterpret_cast<const u4*>(rx + c * VEC));
+          __builtin_memcpy(&v[k], &raw, 16);
+        } else {
+          v[k] = *reinterpret_cast<const Vt*>(rx + c * VEC);
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
@@ -338,7 +346,14 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
         Vt o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = static_cast<T>(one(static_cast<A>(v[k].v[j]), c * VEC + j));
-        *reinterpret_cast<Vt*>(gx + c * VEC) = o;
+        if constexpr (sizeof(Vt) == 16) {
+          using u4 = __attribute__((ext_vector_type(4))) unsigned;
+          u4 raw;
+          __builtin_memcpy(&raw, &o, 16);
+          __builtin_nontemporal_store(raw, reinterpret_cast<u4*>(gx + c * VEC));
+        } else {
+          *reinterpret_cast<Vt*>(gx + c * VEC) = o;
+        }
       }
     }
   }
