@@ -9,8 +9,10 @@ the reference's `throughput-audio-secs-per-sec` (training/caiman_asr_train/train
 
   python bench.py --gpus N --steps K --warmup W
 (for N > 1 the driver launches it under torch.distributed.run, one rank per GPU).
-Rank 0 prints ONE JSON line with `roofline` (dominant hand-written kernel, HIP events) and, at
+Rank 0 prints ONE JSON line with `roofline` (dominant hand-written kernel, HIP events), `lstm_resident`
+(launches of the weight-resident LSTM kernels and their hand-off timeouts: must be 0) and, at
 N = 1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+`CAIMAN_LSTM_RESIDENT=0` selects the per-timestep LSTM launches instead.
 """
 import argparse
 import json
