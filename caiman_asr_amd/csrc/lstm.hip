@@ -557,7 +557,12 @@ __device__ __forceinline__ bool res_wait(unsigned* cnt, unsigned target, unsigne
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 63u) == 0u) {
       if (__hip_atomic_load(fail_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      if (wall_clock64() - t0 > kResTimeoutTicks) {
+      // after a first failure in this process every later wait gives up after 50 ms: a broken set-up cannot turn each of
+      // the ~56 launches of a training step into a 5 s stall (the long limit is for a collective waiting on a slow rank)
+      const long long waited = wall_clock64() - t0;
+      if (waited > kResTimeoutTicks ||
+          (waited > kResTimeoutTicks / 100 && (spins & 1023u) == 0u &&
+           __hip_atomic_load(fail_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
         __hip_atomic_store(fail_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(fail_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
