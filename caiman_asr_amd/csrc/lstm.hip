@@ -1282,6 +1282,7 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
   unsigned* sync = res_begin(st, s);
   if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
@@ -1340,6 +1341,7 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
   unsigned* sync = res_begin(st, s);
   if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
@@ -1512,7 +1514,7 @@ extern "C" int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots)
   const int nks = (int)(H / 32);
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return 0;
   ResState* st = res_state();
-  return (st && (int64_t)n_slots * nks <= st->cus) ? 1 : 0;
+  return (st && (int64_t)n_slots * nks <= st->cus && *reinterpret_cast<volatile unsigned*>(st->fail_host) == 0u) ? 1 : 0;
 }
 
 // Wave calls served by a resident launch since the library was loaded (callers that account launches and bytes

@@ -189,7 +189,7 @@ int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base,
  * and the workgroups of a slot meeting at a device counter once per timestep; other calls keep the per-timestep
  * launches.  Replaces the same time loop (training/lib/csrc/lstm.cu:214-346).  caiman_lstm_resident_mode returns the
  * previous mode; caiman_lstm_resident_failures counts workgroups that timed out waiting (0 in a healthy process; a
- * non-zero value invalidates the results of that launch) and does not synchronise the device;
+ * non-zero value invalidates the results of that launch; from then on the process keeps to the per-timestep launches) and does not synchronise the device;
  * caiman_lstm_resident_launches counts the wave calls served this way. */
 int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
