@@ -1489,6 +1489,19 @@ extern "C" int caiman_lstm_resident_mode(int mode) {
   return caiman::g_res_mode.exchange(mode == 2 ? 2 : (mode ? 1 : 0));
 }
 
+// Overwrites the failure count (0: re-admit the resident kernels after an incident has been dealt with; tests use a
+// non-zero value to check that the process then keeps to the per-timestep kernels).  Returns the previous count.
+extern "C" int caiman_lstm_resident_set_failures(int count) {
+  using namespace caiman;
+  ResState* st = res_state();
+  if (!st) return 0;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  volatile unsigned* f = st->fail_host;
+  const int prev = (int)f[0];
+  f[0] = (unsigned)(count < 0 ? 0 : count);
+  return prev;
+}
+
 // Mode 2 = mode 1 with phase timers in workgroup 0 of slot 0: out[0..4] forward, out[5..9] backward, each
 // {wait for peers, operand row into LDS (+ MFMA stages, backward), MFMA + cell update / epilogue, drain + barrier}
 // in 10 ns ticks summed over timesteps, then the number of timesteps.  Clears the counters.

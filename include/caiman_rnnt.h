@@ -193,6 +193,8 @@ int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base,
  * caiman_lstm_resident_launches counts the wave calls served this way. */
 int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
+/* Overwrite the failure count (0 re-admits the resident kernels after an incident); returns the previous value. */
+int caiman_lstm_resident_set_failures(int count);
 int64_t caiman_lstm_resident_launches(void);
 /* 1 when a multi-timestep wave call with n_slots slots of hidden size H and batch B would be one resident launch on
  * the current device (mode on, B <= 32, H/32 in {2,4,8,16,24,32}, n_slots * H/32 <= CUs). */

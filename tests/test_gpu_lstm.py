@@ -421,3 +421,33 @@ def test_resident_chunk_kernels_hard_activations(T, B, I, H, L):
         scale = b.abs().max().item() + 1e-6
         close = ((a - b).abs() <= (1e-2 if i < 5 else 3e-2) * scale).float().mean().item()
         assert close > 0.995, (i, close)
+
+
+def test_process_falls_back_to_per_timestep_kernels_after_a_handoff_timeout():
+    """A resident launch whose workgroups never met (bounded spin, csrc/lstm.hip) raises the failure count; from then on
+    every wave call is served by the per-timestep kernels until the count is cleared.  The device-side timeout itself
+    cannot be provoked from a test without wedging the GPU for seconds: set the count through the API instead."""
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
+
+    lib = _lib.lib()
+    T, B, I, H, L = 40, 8, 32, 128, 2
+    torch.manual_seed(4)
+    m = CustomLSTM(I, H, L, device=DEV)
+    x = torch.randn(T, B, I, device=DEV)
+    h0 = torch.zeros(L, B, H, device=DEV)
+    c0 = torch.zeros(L, B, H, device=DEV)
+    w = torch.randn(T, B, H, device=DEV)
+    step, _ = _run_stack(m, x, h0, c0, w, torch.bfloat16, 0)
+    assert lib.caiman_lstm_resident_would_run(B, H, L) == 1
+    prev = lib.caiman_lstm_resident_set_failures(1)
+    try:
+        assert lib.caiman_lstm_resident_failures() == 1 and lib.caiman_lstm_resident_would_run(B, H, L) == 0
+        got, n = _run_stack(m, x, h0, c0, w, torch.bfloat16, 1)
+        assert n == 0
+        for a, b in zip(got, step):
+            assert torch.equal(a, b)
+    finally:
+        lib.caiman_lstm_resident_set_failures(prev)
+    _, n = _run_stack(m, x, h0, c0, w, torch.bfloat16, 1)
+    assert n > 0 and lib.caiman_lstm_resident_failures() == prev
