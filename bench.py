@@ -8,16 +8,22 @@ Metric (BASELINE.json): audio-hours/sec = sum over ranks of sum(feat_lens) * 0.0
 the reference's `throughput-audio-secs-per-sec` (training/caiman_asr_train/train.py:379-382) / 3600.
 
   python bench.py --gpus N --steps K --warmup W
-(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU).
+For N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL; started WITHOUT a
+rendezvous environment (`python bench.py --gpus N`) it starts those N ranks itself, as child processes and before
+this process has touched the GPU, and relays rank 0's line (the reference re-launches itself under torchrun the same
+way, training/caiman_asr_train/train_utils/torchrun.py:9-31).  With fewer visible GPUs than ranks the ranks share
+devices over gloo: a plumbing rehearsal, labelled as such in the line, never a measurement.
 Rank 0 prints ONE JSON line with `roofline` (dominant hand-written kernel, HIP events), `lstm_resident`
-(launches of the weight-resident LSTM kernels and their hand-off timeouts: must be 0) and, at
-N = 1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+(launches of the weight-resident LSTM kernels and their hand-off timeouts: must be 0), at N > 1
+`allreduce_exposed_ms` (per step: how long the compute stream stood still waiting for the gradient exchange) and, at
+N = 1, `cpu_baseline` (the CPU oracle timed on the host cores on bounded samples) and `decode` (streaming beam decode,
+2 000 streams: the second half of BASELINE's metric; `--no-decode` skips it).
 `CAIMAN_LSTM_RESIDENT=0` selects the per-timestep LSTM launches instead.
 """
 import argparse
 import json
-import math
 import os
+import subprocess
 import sys
 import time
 from argparse import Namespace
@@ -32,6 +38,7 @@ import torch.distributed as dist
 
 FRAME_SECONDS = 0.03  # 10 ms hop x 3 frame subsampling (training/caiman_asr_train/utils/frame_width.py)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_FILE = "r02_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 BASE_RNNT = dict(  # training/configs/base-8703sp.yaml:73-94
@@ -77,30 +84,134 @@ def make_batches(n_batches, batch_size, seed, n_mels=80):
     return batches
 
 
-def cpu_baseline(model, threads):
-    """The CPU oracle (oracle/model.py + oracle/rnnt_oracle.c: a port, fp32 network / f64 loss) on
-    BASELINE config[0]: base-85M, 2 synthetic 1 s utterances, forward + RNN-T loss + backward."""
-    from oracle import model as omodel
+def _cpu_time(fn, budget_s, max_iters=50):
+    fn()   # warm-up
+    t0, iters = time.perf_counter(), 0
+    while iters < 1 or (time.perf_counter() - t0 < budget_s and iters < max_iters):
+        fn()
+        iters += 1
+    return (time.perf_counter() - t0) / iters, iters
 
-    torch.set_num_threads(threads)
+
+def cpu_baseline(model, threads):
+    """The CPU oracle (oracle/model.py + oracle/rnnt_oracle.c: a port, fp32 network / f64 loss) timed on the host
+    cores, SURVEY section 8(d): BASELINE config[0] (base-85M, 2 synthetic 1 s utterances) forward + RNN-T loss +
+    backward on all of this job's cores (the headline `value`) and, under `variants`, the same on ONE thread (the
+    reference pins OMP_NUM_THREADS=1, training/scripts/train.sh:17), forward + loss only, and a B = 4 slice of the GPU
+    workload (4 LibriSpeech-shaped utterances of the batch the GPU is timed on)."""
+    import math
+
+    from oracle import model as omodel
+    from oracle import native as onative
+
     sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    cfg = dict(BASE_RNNT)
+    blank = N_CLASSES - 1
     rng = np.random.default_rng(0)
     x = rng.standard_normal((34, 2, 240)).astype(np.float32)
     x_lens = np.array([34, 34])
     y = rng.integers(0, N_CLASSES - 1, size=(2, 5))
     y_lens = np.array([5, 3])
-    cfg = dict(BASE_RNNT)
-    omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, N_CLASSES - 1, dtype=torch.float32)  # warm-up
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < 2 or (time.perf_counter() - t0 < 10 and iters < 50):
-        omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, N_CLASSES - 1, dtype=torch.float32)
-        iters += 1
-    dt = (time.perf_counter() - t0) / iters
+
+    def fwd_bwd(x=x, x_lens=x_lens, y=y, y_lens=y_lens):
+        omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, blank, dtype=torch.float32)
+
+    sd_t = {k: torch.tensor(v) for k, v in sd.items()}
+
+    def fwd_only():
+        with torch.no_grad():
+            logits, f_lens = omodel.forward(sd_t, cfg, torch.as_tensor(x), torch.as_tensor(x_lens), torch.as_tensor(y),
+                                            torch.as_tensor(y_lens))
+        onative.transducer_forward(logits.double().numpy(), y.astype(np.int32), f_lens.numpy().astype(np.int32),
+                                   y_lens.astype(np.int32), blank, delay_penalty=0.0, eos_penalty=0.0, eos_idx=None,
+                                   star_lam=math.log(1.0), star_idx=None)
+
     audio_s = float(x_lens.sum()) * FRAME_SECONDS
-    return {"value": audio_s / dt / 3600.0, "unit": "audio-hours/sec", "cores": threads, "kind": "port",
-            "sample": f"base-85M fp32, 2 utterances x 1.02 s (feats [34,2,240], U=[5,3]), fwd+loss+bwd, "
-                      f"{iters} iterations of {dt:.2f} s"}
+    shape = "base-85M fp32, 2 utterances x 1.02 s (feats [34,2,240], U=[5,3])"
+    variants = []
+    torch.set_num_threads(threads)
+    dt, iters = _cpu_time(fwd_bwd, 8.0)
+    out = {"value": audio_s / dt / 3600.0, "unit": "audio-hours/sec", "cores": threads, "kind": "port",
+           "sample": f"{shape}, fwd+loss+bwd, {iters} iterations of {dt:.2f} s"}
+    dt, iters = _cpu_time(fwd_only, 3.0)
+    variants.append({"value": audio_s / dt / 3600.0, "cores": threads, "sample": f"{shape}, fwd+loss only, {iters} x {dt:.2f} s"})
+    torch.set_num_threads(1)
+    dt, iters = _cpu_time(fwd_bwd, 5.0, max_iters=3)
+    variants.append({"value": audio_s / dt / 3600.0, "cores": 1, "sample": f"{shape}, fwd+loss+bwd, {iters} x {dt:.2f} s"})
+    dt, iters = _cpu_time(fwd_only, 3.0, max_iters=3)
+    variants.append({"value": audio_s / dt / 3600.0, "cores": 1, "sample": f"{shape}, fwd+loss only, {iters} x {dt:.2f} s"})
+    torch.set_num_threads(threads)
+    try:   # B = 4 slice of the GPU workload: the first four utterances of this run's first batch, ONE pass
+        feats, frames, txt, ntok = make_batches(1, 4, seed=1)[0]
+        t1 = (frames + 2) // 3
+        T1 = int(t1.max())
+        xs = torch.zeros(T1, 4, 240)
+        for b in range(4):      # frame splicing (stack 3 / subsample 3) on the host, outside the timed pass
+            f = feats[b, :, : int(frames[b])]
+            pad = (-f.shape[1]) % 3
+            f = torch.cat([f, f.new_zeros(80, pad)], 1)
+            xs[: int(t1[b]), b] = f.t().reshape(-1, 240)
+        t0 = time.perf_counter()
+        omodel.loss_and_grads(sd, cfg, xs.numpy(), t1.numpy(), txt.numpy(), ntok.numpy(), blank, dtype=torch.float32)
+        dt = time.perf_counter() - t0
+        a4 = float(t1.sum()) * FRAME_SECONDS
+        variants.append({"value": a4 / dt / 3600.0, "cores": threads,
+                         "sample": f"base-85M fp32, B = 4 slice of the GPU workload ({a4:.0f} s of audio, "
+                                   f"{int(((t1 + 1) // 2 * (ntok + 1)).sum())} lattice cells), fwd+loss+bwd, 1 x {dt:.1f} s"})
+    except Exception as e:   # memory-bound hosts: the slice needs ~10 GB
+        variants.append({"error": repr(e), "sample": "B = 4 slice of the GPU workload"})
+    out["variants"] = variants
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a rendezvous environment: start the N ranks as children of this process
+    (torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Called before anything here has
+    touched the GPU; the children are ordinary child processes, nothing is exec'ed over an initialised process."""
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    for ln in lines:
+        if not ln.lstrip().startswith("{"):
+            print(ln, file=sys.stderr)
+    result = [ln for ln in lines if ln.lstrip().startswith("{")]
+    if result:
+        print(result[-1], flush=True)
+    return proc.returncode if (proc.returncode or result) else 1
+
+
+def decode_record(streams=2000, ticks=100):
+    """Second half of BASELINE's metric (configs[4]): streaming beam decode, `streams` concurrent real-time 16 kHz
+    streams, beam 4 / temperature 1.4 / <= 8 symbols per frame, from audio.  Runs bench_decode.py as a child process with
+    the committed calibration of the synthetic logits (profiles/decode_calibration.json: logit scale and blank bias that
+    make seeded random weights emit speech-like token rates; the fit is deterministic, and the record carries the
+    measured token rate so that the workload can be checked)."""
+    cal = json.load(open(os.path.join(ROOT, "profiles", "decode_calibration.json")))
+    cmd = [sys.executable, os.path.join(ROOT, "bench_decode.py"), "--decoder", "beam", "--streams", str(streams), "--ticks",
+           str(ticks), "--warmup", "10", "--from-audio", "--scale", repr(cal["logit_scale"]), "--blank-bias",
+           repr(cal["blank_bias"])]
+    t0 = time.perf_counter()
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.lstrip().startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"error": (proc.stderr or "no output")[-400:]}
+    d = json.loads(lines[-1])
+    return {"metric": d["metric"], "streams": d["streams"], "real_time": d["real_time"], "tick_audio_ms": d["tick_audio_ms"],
+            "tick_latency_ms": d["tick_latency_ms"], "ticks": d["ticks"], "ticks_over_60ms": d["ticks_over_60ms"],
+            "max_streams_at_p99_linear_estimate": d["max_streams_at_p99_linear_estimate"],
+            "tokens_per_encoder_frame": d["tokens_per_encoder_frame"], "beam_width": d["beam_width"],
+            "temperature": d["temperature"], "max_symbols_per_step": d["max_symbols_per_step"], "input": d["input"],
+            "max_stream_lag_frames": d["max_stream_lag_frames"], "frames_settled_by_cap_frac": d["frames_settled_by_cap_frac"],
+            "calibration": "profiles/decode_calibration.json (logit scale / blank bias of the synthetic weights)",
+            "wall_s_including_model_setup": time.perf_counter() - t0}
 
 
 def main():
@@ -113,10 +224,7 @@ def main():
                     help="base = the headline config (BASELINE configs[1]); large = the 196 M model of configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="weight-gradient GEMMs and the prediction network on side streams (measured: <= 1 %% at batch 32; "
-                         "deadlocks were seen at batch 64+ where more streams share the hardware queues, so it is opt-in)")
-    ap.add_argument("--no-overlap", action="store_true", help="(default now; kept so that old command lines still parse)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the streaming-decode record (N = 1 only)")
     ap.add_argument("--encoder-pipe", type=int, default=1,
                     help="1: pre_rnn -> StackTime -> post_rnn as one layer pipeline (encoder_pipe.py); 2: with the prediction "
                          "network's steps in the same launches (measured: 38.58 vs 38.55 ms, no gain); 0: stack after stack")
@@ -125,20 +233,30 @@ def main():
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)     # nothing in this process has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    rehearsal = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # CAIMAN_DIST_BACKEND=gloo is a rehearsal aid (several ranks sharing one GPU); the real path is RCCL
-        backend = os.environ.get("CAIMAN_DIST_BACKEND", "nccl")
-        n_dev = torch.cuda.device_count()
+        n_dev = torch.cuda.device_count()      # does not initialise the GPU
+        # the real path is RCCL, one rank per GPU; with fewer GPUs than ranks (a 1-GPU box) the ranks share devices over
+        # gloo so that the N > 1 code path can be rehearsed: same code, different backend string, not a measurement
+        backend = os.environ.get("CAIMAN_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             local_rank = local_rank % max(n_dev, 1)
             dist.init_process_group(backend)
+        if n_dev < world:
+            rehearsal = f"{world} ranks sharing {n_dev} GPU(s) over {backend}: plumbing rehearsal, not a measurement"
+            # weight-resident LSTM grids of two PROCESSES would each hold part of one chip and wait for the rest
+            os.environ["CAIMAN_LSTM_RESIDENT"] = "0"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -148,7 +266,6 @@ def main():
     from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers, get_packing_meta_data
     from caiman_asr_amd.rnnt.model import RNNT
     from caiman_asr_amd.train_utils.distributed import FlatGradReducer, broadcast_parameters
-    from caiman_asr_amd.train_utils import overlap
     from caiman_asr_amd.train_utils.lr import lr_policy
     from caiman_asr_amd.train_utils.optimizer import build_optimizer
 
@@ -165,16 +282,14 @@ def main():
     model.joint_fc_nt_backward = os.environ.get("CAIMAN_JOINT_NT", "1") != "0"
     model.encoder_pipe = args.encoder_pipe >= 1
     model.pred_in_encoder_pipe = args.encoder_pipe >= 2
-    model.overlap_weight_grads = args.overlap and not args.no_overlap
-    model.parallel_prediction = args.overlap and not args.no_overlap
-    from caiman_asr_amd.rnnt_ext.custom_lstm import stack as lstm_stack
-
-    lstm_stack.OVERLAP_WEIGHT_GRADS = args.overlap and not args.no_overlap
     opt_args = Namespace(lr=4e-3, weight_decay=1e-2, beta1=0.9, beta2=0.999, clip_norm=1.0, ema=0.999)
     optimizer = build_optimizer(opt_args, model)
     initial_lrs = [g["lr"] for g in optimizer.param_groups]
     broadcast_parameters(optimizer.flat_p)
-    reducer = FlatGradReducer(optimizer._params, optimizer._offsets, optimizer.flat_g) if world > 1 else None
+    reducer = None
+    if world > 1:
+        reducer = FlatGradReducer(optimizer._params, optimizer._offsets, optimizer.flat_g, measure_exposed=True)
+        reducer.attach(model).guard_handoffs(optimizer)
     loss_fn = ApexTransducerLoss(blank_idx=N_CLASSES - 1, eos_idx=None, star_idx=None, packed_input=True,
                                  validate_first_n_remaining=0)
     spec = SpecAugment(freq_masks=2, min_freq=0, max_freq=20, time_masks=10, min_time=0, max_time=0.03)
@@ -202,7 +317,6 @@ def main():
             loss = loss_fn(logits, logit_lens, txt, txt_lens_d, meta["batch_offset"], meta["max_f_len"], loss_mods)
         del logits
         loss.backward()   # a NaN loss gives NaN gradients -> the optimiser skips the update on-device
-        overlap.wait_all()  # side-stream weight-gradient GEMMs must land before the gradients are used
         if reducer is not None:
             reducer.finish()
         optimizer.step(zero_grad=True)
@@ -253,6 +367,8 @@ def main():
         if i == 0:
             loss_fn.t_loss.validate_lengths = False  # inputs validated once; no per-step host syncs
     barrier()
+    if reducer is not None:
+        reducer.exposed_ms()   # drop the warm-up steps' events
     if not args.no_kernel_timing:
         _lib.timing.enabled = True
         _lib.timing.sample_every = {"lstm_fwd": 16, "lstm_bwd": 16}   # see _lib._Timing: every bracket would cost 13 %
@@ -281,13 +397,16 @@ def main():
     _lib.timing.enabled = False
     log(f"{args.steps} timed steps in {elapsed:.3f} s")
 
-    stats = torch.tensor([elapsed, audio_s], dtype=torch.float64, device=dev)
+    exposed_ms = reducer.exposed_ms() / args.steps if reducer is not None else 0.0
+    stats = torch.tensor([elapsed, audio_s, exposed_ms], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         asum = stats[1:2].clone()
         dist.all_reduce(asum, op=dist.ReduceOp.SUM)
-        elapsed, audio_total = float(tmax.item()), float(asum.item())
+        emax = stats[2:3].clone()
+        dist.all_reduce(emax, op=dist.ReduceOp.MAX)
+        elapsed, audio_total, exposed_ms = float(tmax.item()), float(asum.item()), float(emax.item())
     else:
         audio_total = audio_s
 
@@ -304,8 +423,18 @@ def main():
                                    "large-196M RNN-T bf16 training + on-GPU SpecAugment (BASELINE.json configs[3] shapes)",
                        "global_batch": args.batch * world, "utterance_seconds": "clip(N(12.3,3.8),1,16.7)",
                        "parallelism": f"dp{world}", "final_loss": loss_val,
-                       "audio_seconds_per_step": audio_total / args.steps},
+                       "audio_seconds_per_step": audio_total / args.steps,
+                       "timed_step": "on-device SpecAugment + frame splicing + fwd + loss + bwd + (gradient all-reduce) + "
+                                     "LAMB/EMA; inputs are log-mel features [B,80,T] resident in HBM: the log-mel "
+                                     "frontend / audio decode run outside the timed step (tools/feed_bench.py measures "
+                                     "the feed separately)"},
         }
+        if world > 1:
+            out["allreduce_exposed_ms"] = exposed_ms    # per step, max over ranks: compute stream idle in reducer.finish()
+            out["gradient_exchange"] = {"bytes_per_step": int(optimizer.flat_g.numel()) * 4, "collectives_per_step": len(reducer.buckets),
+                                        "backend": dist.get_backend()}
+        if rehearsal:
+            out["rehearsal"] = rehearsal
         if not args.no_kernel_timing:
             summ = _lib.timing_summary()
             out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in summ.items()}
@@ -320,31 +449,28 @@ def main():
                 resident = launches < 1.5 * brackets
                 kname = "lstm_bwd_resident" if resident else "lstm_bwd_step_mfma"
                 achieved = nbytes / (ms * 1e-3) / 1e9
-                traffic = None  # PMC counters need their own rocprofv3 passes: read the committed measurement
-                try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                    traffic = pmc[kname]["traffic_bytes_per_launch"]
-                except Exception:
-                    pass
+                # The resident kernel is a chain of dependent timesteps, not a stream: the figure that moves is the time per
+                # timestep against the MFMA floor of one timestep (8*B*H^2 FLOP of one layer on its 32 CUs' matrix cores).
+                us_ts = ms * 1e3 / tsteps
                 out["roofline"] = {"kernel": (kname + (" (all backward timesteps of one pipeline tick, every active LSTM layer, per launch)"
                                                        if resident else " (one backward timestep of all pipelined LSTM layers per launch)")),
                                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                    "avg_launch_us": ms * 1e3 / launches, "launches": launches,
                                    "algorithmic_bytes_per_launch": nbytes / launches,
-                                   "us_per_timestep": ms * 1e3 / tsteps,
-                                   "note": ("avg_launch_us is event-to-event over sampled brackets (kernel + its counter memset + "
-                                            "the events' own cost); the kernel alone is `rocprof_kernel_avg_us` (profiles/). "
-                                            "The resident kernel is bounded by its chain of dependent timesteps (hand-off of "
-                                            "the dG row between the workgroups of a layer), not by HBM: DESIGN.md section 4")}
-                try:   # the committed rocprofv3 --kernel-trace --stats summary of this command
-                    import csv
-
-                    with open(os.path.join(ROOT, "profiles", "r01_bench_v13_kernel_stats.csv")) as f:
-                        hits = [(int(row["Calls"]), float(row["TotalDurationNs"])) for row in csv.DictReader(f) if kname in row["Name"]]
-                    # every instantiation of the kernel (encoder H = 1024 and the prediction network's narrower launches),
-                    # as the live bracket sees them
-                    out["roofline"]["rocprof_kernel_avg_us"] = sum(t for _, t in hits) / sum(c for c, _ in hits) / 1e3
+                                   "chain": {"us_per_timestep": us_ts, "mfma_floor_us_per_timestep": 0.85,
+                                             "frac_of_floor": 0.85 / us_ts},
+                                   "note": ("live HIP-event measurement; avg_launch_us is event-to-event over sampled brackets "
+                                            "(kernel + its counter memset + the events' own cost).  `bound` names the roofline the "
+                                            "algorithmic bytes are priced against; the kernel itself is bounded by its chain of "
+                                            "dependent timesteps (hand-off of the dG row between the workgroups of a layer): "
+                                            "`chain`, DESIGN.md section 4")}
+                try:   # builder-run rocprofv3 figures of the same command, committed under profiles/: constants on this box
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+                    out["roofline"]["from_profiles"] = {"source": f"profiles/{PMC_FILE} (builder-run rocprofv3 --pmc / --kernel-trace "
+                                                                  "passes, NOT measured in this run)",
+                                                        "traffic_bytes_per_launch": pmc[kname]["traffic_bytes_per_launch"],
+                                                        "rocprof_kernel_avg_us": pmc[kname].get("rocprof_kernel_avg_us")}
                 except Exception:
                     pass
             if "loss_bwd" in summ:
@@ -357,6 +483,12 @@ def main():
         native = _lib.lib()
         out["lstm_resident"] = {"launches": int(native.caiman_lstm_resident_launches()),
                                 "handoff_timeouts": int(native.caiman_lstm_resident_failures())}   # must be 0
+        if world == 1 and not args.no_decode and args.model == "base":
+            try:
+                log("decode record (child process)")
+                out["decode"] = decode_record()
+            except Exception as e:
+                out["decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # the box exposes more logical CPUs than this job's share (16 per GPU): oversubscribing
@@ -372,4 +504,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

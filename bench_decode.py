@@ -49,7 +49,14 @@ def main():
                     help="beam: serving safeguard, settle a frame after this many expansions of one stream (0 = off)")
     ap.add_argument("--pred-weight", type=float, default=0.1, help="damping of the prediction network's joint projection")
     ap.add_argument("--profile-host", action="store_true", help="beam: split the tick into host / device parts")
+    ap.add_argument("--scale", type=float, default=None,
+                    help="with --blank-bias: skip the closed-loop fit and use these logit scale / blank bias (the fit is "
+                         "deterministic for the seeded random weights; bench.py passes the committed values of "
+                         "profiles/decode_calibration.json so that its decode record costs seconds, and the record "
+                         "carries the MEASURED tokens per frame so the workload can be checked)")
+    ap.add_argument("--blank-bias", type=float, default=None)
     args = ap.parse_args()
+    fixed = args.scale is not None and args.blank_bias is not None
     from caiman_asr_amd import _lib
     from caiman_asr_amd.rnnt.decoder import StreamingGreedyDecoder
     from caiman_asr_amd.rnnt.model import RNNT
@@ -164,7 +171,12 @@ def main():
                 set_scale(sc, 0.5 * (lo + hi))
             return 0.5 * (lo + hi)
 
-        if args.top1_prob > 0:
+        bias = None
+        if fixed:
+            scale, bias = args.scale, args.blank_bias
+            with torch.no_grad():
+                set_scale(scale, bias)
+        elif args.top1_prob > 0:
             scale *= 8.0
             for _ in range(6):
                 bias = fit_blank_bias(scale)
@@ -175,7 +187,7 @@ def main():
                     break
                 scale /= 1.8
         else:
-            fit_blank_bias(scale)
+            bias = fit_blank_bias(scale)
         dec = new_decoder(args.streams, cutoff=int(args.straggler_frac * args.streams), raw=True)   # records, not Python objects
     else:
         # closed loop on short greedy decodes: bisect the blank bias until `emit_rate` tokens per frame are emitted
@@ -196,7 +208,11 @@ def main():
                 set_scale(scale, b)
             return greedy_rate()
 
-        if not args.no_calibrate:
+        if fixed:
+            scale = args.scale
+            with torch.no_grad():
+                set_scale(scale, args.blank_bias)
+        elif not args.no_calibrate:
             b0, step = blank_shift(scale), max(1.0, 0.5 * scale * float(raw[:, :-1].std()))
             lo = hi = b0
             for _ in range(16):
@@ -283,7 +299,8 @@ def main():
             "max_expansions_per_frame": args.max_expansions,
             "frames_settled_by_cap_frac": dec.search.capped_frames() / max(dec.n_frames * args.streams, 1),
             "straggler_frac": args.straggler_frac, "tick_budget_ms": args.tick_budget_ms, "max_stream_lag_frames": max(lags), "mean_max_lag_frames": sum(lags) / len(lags),
-            "synthetic_top1_prob_target": args.top1_prob, "logit_scale": scale,
+            "synthetic_top1_prob_target": args.top1_prob, "logit_scale": scale, "blank_bias": bias,
+            "calibration": "fixed (--scale / --blank-bias)" if fixed else "closed loop in this run",
             **({"measured_mean_top1_prob": dec.dec.step.stats[0] / max(dec.dec.step.stats[1], 1),
                 "expansions_per_stream_frame": dec.dec.profile["expansions"] / (args.ticks * args.streams)}
                if args.profile_host else {})} if args.decoder == "beam" else {}),

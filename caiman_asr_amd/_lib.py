@@ -122,6 +122,7 @@ _SIGS = {
     "caiman_lstm_resident_mode": ([I32], ctypes.c_int),
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
     "caiman_lstm_resident_set_failures": ([I32], ctypes.c_int),
+    "caiman_lstm_resident_poison": ([P, P, P], ctypes.c_int),
     "caiman_lstm_resident_launches": ([], ctypes.c_int64),
     "caiman_lstm_resident_would_run": ([I64, I64, I32], ctypes.c_int),
     "caiman_lstm_resident_profile": ([P], ctypes.c_int),

@@ -23,6 +23,6 @@ int check_launch(const char* what) {
 
 }  // namespace caiman
 
-extern "C" int caiman_abi_version(void) { return 3; }
+extern "C" int caiman_abi_version(void) { return 4; }
 extern "C" const char* caiman_last_error(void) { return caiman::g_err; }
 extern "C" int caiman_built_for_gfx950(void) { return 1; }

@@ -42,6 +42,10 @@ __device__ __forceinline__ T from_acc(A v) {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Device-visible address of the current device's resident-LSTM failure word (csrc/lstm.hip: host-mapped memory that
+// counts hand-off timeouts), or nullptr while no resident launch has been attempted on this device.
+const unsigned* resident_fail_word();
+
 #define CAIMAN_CHECK(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

@@ -1453,6 +1453,33 @@ int run_bwd(const T* R, const T* gates, const T* c, const T* delta, int64_t d_st
 }  // namespace
 }  // namespace caiman
 
+namespace caiman {
+const unsigned* resident_fail_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  return g_res[dev].ok ? g_res[dev].fail_host : nullptr;
+}
+namespace {
+__global__ void resident_poison_kernel(float* grad, const unsigned* fail_word, const unsigned* seen) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *fail_word > *seen) *grad = __builtin_nanf("");
+}
+}  // namespace
+}  // namespace caiman
+
+// Data-parallel runs: a hand-off timeout on ONE rank must make EVERY rank drop the optimiser step.  Queued in front of
+// the all-reduce of the gradient slice that holds `grad_elem`, this writes a NaN there when the failure count has
+// moved past `*seen` (the count caiman_lamb_step recorded at its last call: work[5] of its scratch, as uint32); the
+// sum carries the NaN to every rank and each rank's caiman_lamb_step skips the update (non-finite gradient norm).
+extern "C" int caiman_lstm_resident_poison(float* grad_elem, const uint32_t* seen, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(grad_elem && seen, "lstm_resident_poison: null pointer");
+  const unsigned* fw = resident_fail_word();
+  if (!fw) return CAIMAN_OK;   // no resident launch was ever attempted on this device
+  hipLaunchKernelGGL(resident_poison_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), grad_elem, fw, seen);
+  return check_launch("caiman_lstm_resident_poison");
+}
+
 extern "C" int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backward) {
   if (B < 1 || H < 1) return 0;
   const int64_t bp = (B + 31) / 32 * 32;

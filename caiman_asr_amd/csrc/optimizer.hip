@@ -23,7 +23,8 @@ namespace {
 
 constexpr int kOptThreads = 256;
 
-// ctl layout (floats): [0]=gnorm [1]=clip_div [2]=finite(1/0) [3]=bc1 [4]=bc2
+// ctl layout (floats): [0]=gnorm [1]=clip_div [2]=apply(1/0) [3]=bc1 [4]=bc2 [5]=(uint32) resident-LSTM failure count
+// seen at the last call [6]=1 if THIS call was dropped because that count had moved
 __global__ __launch_bounds__(kOptThreads) void gnorm_partial_kernel(const float* __restrict__ g,
                                                                     const int64_t* __restrict__ chunk_start,
                                                                     const int32_t* __restrict__ chunk_len,
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(kOptThreads) void gnorm_partial_kernel(const float*
 __global__ __launch_bounds__(1024) void gnorm_final_kernel(const float* __restrict__ partial, int64_t n,
                                                            float inv_scale, float max_norm, float beta1,
                                                            float beta2, int bias_correction,
+                                                           const unsigned* __restrict__ fail_word,
                                                            int32_t* __restrict__ step, float* __restrict__ ctl) {
   __shared__ double sm[1024 / kWave];
   double acc = 0;
@@ -52,7 +54,14 @@ __global__ __launch_bounds__(1024) void gnorm_final_kernel(const float* __restri
   acc = block_reduce<1024 / kWave>(acc, [](double a, double b) { return a + b; }, sm);
   if (threadIdx.x == 0) {
     const float gnorm = (float)sqrt(acc) * inv_scale;
-    const bool finite = isfinite(gnorm);
+    // A weight-resident LSTM launch whose hand-off timed out since the last call left stale (finite) rows behind:
+    // that step is dropped like a non-finite one (reference behaviour for a bad step: train.py:274-284).
+    unsigned* seen = reinterpret_cast<unsigned*>(ctl) + 5;
+    const unsigned fails = fail_word ? __hip_atomic_load(fail_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *seen;
+    const bool handoff_ok = fails <= *seen;
+    *seen = fails;
+    ctl[6] = handoff_ok ? 0.f : 1.f;
+    const bool finite = isfinite(gnorm) && handoff_ok;
     int st = *step;
     if (finite) { st += 1; *step = st; }
     ctl[0] = gnorm;
@@ -205,7 +214,7 @@ extern "C" int caiman_lamb_step(float* p, float* g, float* m, float* v, float* e
   hipLaunchKernelGGL(gnorm_partial_kernel, dim3((unsigned)n_chunks), dim3(kOptThreads), 0, st, g, chunk_start,
                      chunk_len, part0);
   hipLaunchKernelGGL(gnorm_final_kernel, dim3(1), dim3(1024), 0, st, part0, n_chunks, inv_grad_scale, max_grad_norm,
-                     beta1, beta2, bias_correction, step_counter, ctl);
+                     beta1, beta2, bias_correction, resident_fail_word(), step_counter, ctl);
   hipLaunchKernelGGL(lamb_stage1_kernel, dim3((unsigned)n_chunks), dim3(kOptThreads), 0, st, a, ctl, part0, part1);
   hipLaunchKernelGGL(lamb_ratio_kernel, dim3((unsigned)((n_tensors + 3) / 4)), dim3(256), 0, st, a, ctl,
                      tensor_first_chunk, n_tensors, part0, part1, ratio);

@@ -59,12 +59,6 @@ class RNNT(nn.Module):
         self.encoder_pipe = True    # one layer pipeline across pre_rnn / StackTime / post_rnn when the stacks allow it
         self.joint_fc_nt_backward = True   # input gradient of the joint projection against a [K, N] weight copy (10 % faster GEMM)
         self.pred_in_encoder_pipe = False  # opt-in: the prediction network's LSTM steps in the same launches (measured: no gain)
-        # opt-in: joint_fc's weight gradient runs on a side stream (train_utils/overlap.py); the training
-        # loop must call overlap.wait_all() before it reads the gradients
-        self.overlap_weight_grads = False
-        # opt-in: prediction network on a second stream, concurrent with the encoder
-        self.parallel_prediction = False
-        self._pred_stream = None
 
         common = dict(forget_gate_bias=forget_gate_bias, custom_lstm=custom_lstm, quantize=quantize,
                       hidden_hidden_bias_scale=hidden_hidden_bias_scale, weights_init_scale=weights_init_scale,
@@ -107,22 +101,8 @@ class RNNT(nn.Module):
             out = self._enc_pred_one_pipeline(x, x_lens, y, y_lens, pred_net_state, enc_state)
             if out is not None:
                 return out
-        if not (self.parallel_prediction and x.is_cuda):
-            return self.enc_pred_static(x, x_lens, y, y_lens, self.encode, self.predict,
-                                        pred_net_state=pred_net_state, enc_state=enc_state)
-        # same wiring as enc_pred_static, with the (short) prediction network enqueued first on its own stream
-        y = label_collate(y)
-        g, _, all_pred_hid = self._predict_on_side_stream(
-            y, pred_state=(pred_net_state.next_to_last_pred_state if pred_net_state else None), add_sos=True,
-            special_sos=pred_net_state.last_token if pred_net_state else None)
-        f, x_lens, new_enc_state = self.encode(x, x_lens, enc_state=enc_state)
-        torch.cuda.current_stream().wait_stream(self._pred_stream)
-        g_lens = y_lens + 1
-        new_pred = get_pred_net_state(y, all_pred_hid, y_lens, g_lens)
-        rnnt_state = None
-        if new_enc_state is not None and new_pred is not None:
-            rnnt_state = RNNTState(enc_state=new_enc_state, pred_net_state=new_pred)
-        return (f, x_lens), (g, g_lens), rnnt_state
+        return self.enc_pred_static(x, x_lens, y, y_lens, self.encode, self.predict,
+                                    pred_net_state=pred_net_state, enc_state=enc_state)
 
     def _enc_pred_one_pipeline(self, x, x_lens, y, y_lens, pred_net_state, enc_state):
         """Encoder and prediction network in the same LSTM launches (encoder_pipe.py); None if not covered."""
@@ -150,19 +130,6 @@ class RNNT(nn.Module):
         new_pred = get_pred_net_state(y, all_pred, y_lens, g_lens)
         state = RNNTState(enc_state=new_enc, pred_net_state=new_pred) if new_pred is not None else None
         return (f, lens2), (g, g_lens), state
-
-    def _predict_on_side_stream(self, *args, **kwargs):
-        """The prediction network does not depend on the encoder: run it (forward, and through autograd its
-        backward) on a second HIP stream so its latency-bound LSTM steps overlap the encoder's."""
-        if getattr(self, "_pred_stream", None) is None:
-            self._pred_stream = torch.cuda.Stream()
-        main = torch.cuda.current_stream()
-        self._pred_stream.wait_stream(main)
-        with torch.cuda.stream(self._pred_stream):
-            g, hid, all_hid = self.predict(*args, **kwargs)
-        for t in (g, *hid, *(all_hid or ())):
-            t.record_stream(main)
-        return g, hid, all_hid
 
     @staticmethod
     def enc_pred_static(x, x_lens, y, y_lens, encode, predict, pred_net_state: Optional[PredNetState] = None,
@@ -271,10 +238,6 @@ class RNNT(nn.Module):
             h = self.apex_joint(f, g, f_len, g_len, batch_offset=batch_offset, packed_batch=packed_batch)
             if not self.apex_joint.relu:
                 h = self.relu_drop(h)
-        if self.overlap_weight_grads and self.training and h.is_cuda and torch.is_grad_enabled():
-            from caiman_asr_amd.train_utils.overlap import linear_overlapped
-
-            return linear_overlapped(h, self.joint_fc.weight, self.joint_fc.bias)
         if self.training and h.is_cuda and torch.is_grad_enabled() and h.dtype in (torch.float16, torch.bfloat16) \
                 and self.joint_fc_nt_backward:
             from caiman_asr_amd.train_utils.overlap import linear_transposed_backward

@@ -243,7 +243,6 @@ class EncoderPipeFunction(torch.autograd.Function):
         Le, Lp, T1p = La + Lb, L - La - Lb, T2 * f
         from caiman_asr_amd.train_utils import overlap
 
-        overlap.flush_deferred()
         overlap.fence_collectives()   # resident launches and a collective's kernel must not be placed by halves together
         saved = list(ctx.saved_tensors)
         x, Ga, Gb, Ya, Yb, Ca, Cb = saved[:7]
@@ -375,8 +374,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             if param.grad is None:
                 param.grad = torch.zeros_like(param)
             param.grad.view(4, hl, *param.shape[1:]).add_(g.view(hl, 4, *g.shape[1:]).transpose(0, 1))
-            for cb in overlap._grad_ready_callbacks:
-                cb(param)
+            overlap.notify_grad_ready(param)
 
         # post layers have identical shapes: their recurrent-weight gradients (all Lb), their input-weight gradients
         # (layers 1..Lb-1) and all bias gradients are three batched calls instead of 3 * Lb

@@ -1,10 +1,13 @@
-"""rnnt_ext.transducer.loss — RNN-T transducer loss module + autograd function.
+"""rnnt_ext.transducer.loss — RNN-T transducer loss module + autograd function on the gfx950 C-ABI library.
 
-Interface mirror of training/lib/src/rnnt_ext/transducer/loss.py:43-253 (class names,
-argument order, defaults, assertions); the compute is the gfx950 C-ABI library
-(caiman_logsumexp, caiman_transducer_loss_forward / _backward).
+Drop-in for the public surface of training/lib/src/rnnt_ext/transducer/loss.py:43-253 — `TransducerLoss(packed_input)`
+with the same `forward` keywords and defaults, `TransducerLossFunc.apply` with the same positional order — so the
+reference's callers (training/caiman_asr_train/rnnt/loss.py:68-127) and tests read unchanged.  The body is this
+repo's own: one immutable record carries the call's scalars from forward to backward, the sentinel / sanity rules
+live in one helper, and the compute is caiman_logsumexp + caiman_transducer_loss_forward / _backward.
 """
 import math
+from dataclasses import dataclass
 from typing import List, Optional
 
 import torch
@@ -12,108 +15,115 @@ import torch
 import caiman_asr_amd.rnnt_ext.cuda.logsumexp as logsumexp_cu
 import caiman_asr_amd.rnnt_ext.cuda.transducer_loss as transducer_loss_cu
 
+_NO_EOS, _NO_STAR = -1, -2   # sentinels the kernels understand as "feature off" (transducer_loss.cu:396-501)
+
+
+@dataclass(frozen=True)
+class _LossCall:
+    """Scalars of one loss evaluation, in the units the kernels take them."""
+    delay_penalty: float
+    max_f_len: int
+    blank_idx: int
+    eos_penalty: float
+    eos_idx: int
+    log_star_penalty: float
+    star_idx: int
+    packed: bool
+
+    def kernel_args(self):
+        return (self.delay_penalty, self.max_f_len, self.blank_idx, self.eos_penalty, self.eos_idx,
+                self.log_star_penalty, self.star_idx, self.packed)
+
+
+def _special_indices(blank_idx: int, eos_idx: Optional[int], star_idx: Optional[int]):
+    """None -> the kernels' sentinels; blank, EOS and star must be three different classes."""
+    eos = _NO_EOS if eos_idx is None else int(eos_idx)
+    star = _NO_STAR if star_idx is None else int(star_idx)
+    for name, idx in (("eos_idx", eos), ("star_idx", star)):
+        if idx == blank_idx:
+            raise AssertionError(f"{name} must be different from blank_idx")
+    if star == eos:
+        raise AssertionError("star_idx must be different from eos_idx")
+    return eos, star
+
 
 class TransducerLoss(torch.nn.Module):
-    """Transducer loss (Graves 2012) with delay / EOS / star penalties.
+    """Per-utterance transducer loss (Graves 2012) with delay / EOS / star penalties.
 
-    Arguments:
-        packed_input: whether the logits arrive packed ([sum_b T_b*(U_b+1), V], don't-care
-            cells removed) instead of padded [B, T, U+1, V].
+    packed_input: logits arrive as [sum_b T_b*(U_b+1), V] (don't-care cells removed) instead of [B, T, U+1, V];
+    `batch_offset` (cumulative cell counts) and `max_f_len` are then required.
     """
 
     def __init__(self, packed_input: bool = False):
         super().__init__()
         self.packed_input = packed_input
         self.dummy_batch_offset = torch.empty(0)
-        # The reference asserts on device tensors every call (loss.py:115-119): three host syncs per
-        # step.  Same checks by default; a training loop that has validated its loader may clear this.
+        # The reference checks its length tensors on the host in every call (three device syncs per step).  Same
+        # checks by default; a training loop that has validated its loader clears this after the first step.
         self.validate_lengths = True
 
-    def forward(
-        self,
-        x: torch.Tensor,
-        label: torch.Tensor,
-        f_len: torch.Tensor,
-        y_len: torch.Tensor,
-        blank_idx: int,
-        eos_idx: Optional[int] = None,
-        star_idx: Optional[int] = None,
-        batch_offset: Optional[torch.Tensor] = None,
-        max_f_len: Optional[int] = None,
-        debug_list: Optional[List[torch.Tensor]] = None,
-        delay_penalty: float = 0.0,
-        eos_penalty: float = 0.0,
-        star_penalty: float = 1.0,
-    ) -> torch.Tensor:
-        """Returns the per-utterance loss, shape (B,).  Argument meaning as in the reference
-        (training/lib/src/rnnt_ext/transducer/loss.py:78-113)."""
-        assert len(x.shape) == 4 or len(x.shape) == 2, "Shape (B, T, U, H) or (*, H)"
-        if self.validate_lengths:
-            assert f_len.min() >= 1, "f_len must be non-negative"
-            assert y_len.min() >= 0, "y_len must be non-negative"
-            assert y_len.max() <= label.size(1), "y_len must be less than label length"
+    def _check_lengths(self, label, f_len, y_len, max_f_len):
+        lo_f, lo_y, hi_y, hi_f = (int(v) for v in torch.stack(
+            [f_len.min(), y_len.min(), y_len.max(), f_len.max()]).tolist())    # one sync for all four
+        if lo_f < 1:
+            raise AssertionError("f_len must be non-negative")
+        if lo_y < 0:
+            raise AssertionError("y_len must be non-negative")
+        if hi_y > label.size(1):
+            raise AssertionError("y_len must be less than label length")
+        if self.packed_input and max_f_len != hi_f:
+            raise AssertionError(f"max_f_len ({max_f_len}) must equal f_len.max() ({hi_f})")
 
+    def forward(self, x: torch.Tensor, label: torch.Tensor, f_len: torch.Tensor, y_len: torch.Tensor, blank_idx: int,
+                eos_idx: Optional[int] = None, star_idx: Optional[int] = None,
+                batch_offset: Optional[torch.Tensor] = None, max_f_len: Optional[int] = None,
+                debug_list: Optional[List[torch.Tensor]] = None, delay_penalty: float = 0.0, eos_penalty: float = 0.0,
+                star_penalty: float = 1.0) -> torch.Tensor:
+        """-> loss [B].  x: logits (padded 4-D or packed 2-D); label [B, Umax] int32; f_len / y_len [B] int32;
+        `debug_list == []` receives [alpha, beta]."""
+        if x.dim() not in (2, 4):
+            raise AssertionError("Shape (B, T, U, H) or (*, H)")
         if self.packed_input:
             if batch_offset is None or max_f_len is None:
                 raise Exception("Please specify batch_offset and max_f_len when packing is enabled")
-            my_batch_offset = batch_offset
-            my_max_f_len = max_f_len
-            if self.validate_lengths:
-                assert my_max_f_len == f_len.max()
         else:
-            my_batch_offset = self.dummy_batch_offset
-            my_max_f_len = x.size(1)
-
-        return TransducerLossFunc.apply(
-            x, label, f_len, y_len, my_batch_offset, delay_penalty, my_max_f_len, blank_idx,
-            eos_penalty, eos_idx, math.log(star_penalty), star_idx, debug_list, self.packed_input)
+            batch_offset, max_f_len = self.dummy_batch_offset, x.size(1)
+        if self.validate_lengths:
+            self._check_lengths(label, f_len, y_len, max_f_len)
+        return TransducerLossFunc.apply(x, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx,
+                                        eos_penalty, eos_idx, math.log(star_penalty), star_idx, debug_list,
+                                        self.packed_input)
 
 
 class TransducerLossFunc(torch.autograd.Function):
+    """apply(x, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx, eos_penalty, eos_idx,
+    star_penalty (already a log), star_idx, debug_list, packed_input) -> loss [B]; gradient flows to x only."""
+
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx,
-                eos_penalty, eos_idx, star_penalty, star_idx, debug_list, packed_input):
-        if packed_input:
-            denom = logsumexp_cu.logsumexp(x, 128, True)
+    def forward(ctx, x, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx, eos_penalty, eos_idx,
+                star_penalty, star_idx, debug_list, packed_input):
+        eos, star = _special_indices(blank_idx, eos_idx, star_idx)
+        call = _LossCall(float(delay_penalty), int(max_f_len), int(blank_idx), float(eos_penalty), eos,
+                         float(star_penalty), star, bool(packed_input))
+        if call.packed:
+            rows = x
         else:
-            assert x.is_contiguous(), "activations must be contiguous or packed"
-            denom = logsumexp_cu.logsumexp(x.view(-1, x.shape[-1]), 128, True).view(x.shape[:-1])
-        assert denom.shape == x.shape[:-1]
-
-        if eos_idx is None:
-            eos_idx = -1
-        else:
-            assert eos_idx != blank_idx, "eos_idx must be different from blank_idx"
-        if star_idx is None:
-            star_idx = -2
-        else:
-            assert star_idx != blank_idx, "star_idx must be different from blank_idx"
-        assert star_idx != eos_idx, "star_idx must be different from eos_idx"
-
-        alpha, beta, loss = transducer_loss_cu.forward(
-            x, denom, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx,
-            eos_penalty, eos_idx, star_penalty, star_idx, packed_input)
-
-        if debug_list == []:
-            debug_list += [alpha, beta]
+            if not x.is_contiguous():
+                raise AssertionError("activations must be contiguous or packed")
+            rows = x.view(-1, x.shape[-1])
+        denom = logsumexp_cu.logsumexp(rows, 128, True).view(x.shape[:-1])   # log-normaliser of every lattice cell
+        alpha, beta, loss = transducer_loss_cu.forward(x, denom, label, f_len, y_len, batch_offset, *call.kernel_args())
+        if debug_list is not None and len(debug_list) == 0:
+            debug_list.extend((alpha, beta))
         ctx.save_for_backward(x, denom, alpha, beta, f_len, y_len, label, batch_offset)
-        ctx.blank_idx = blank_idx
-        ctx.eos_penalty = eos_penalty
-        ctx.eos_idx = eos_idx
-        ctx.star_penalty = star_penalty
-        ctx.star_idx = star_idx
-        ctx.packed_input = packed_input
-        ctx.max_f_len = max_f_len
-        ctx.delay_penalty = delay_penalty
+        ctx.call = call
         return loss
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, loss_grad):
         x, denom, alpha, beta, f_len, y_len, label, batch_offset = ctx.saved_tensors
-        x_grad = transducer_loss_cu.backward(
-            x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len, label, batch_offset,
-            ctx.delay_penalty, ctx.max_f_len, ctx.blank_idx, ctx.eos_penalty, ctx.eos_idx,
-            ctx.star_penalty, ctx.star_idx, ctx.packed_input)
-        return x_grad, *([None] * 13)
+        x_grad = transducer_loss_cu.backward(x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len, label,
+                                             batch_offset, *ctx.call.kernel_args())
+        return (x_grad,) + (None,) * 13

@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import torch
 
 from caiman_asr_amd.rnnt.loss import LossModifiers, get_packing_meta_data
-from caiman_asr_amd.train_utils.core import is_loss_nan, unwrap
+from caiman_asr_amd.train_utils.core import is_loss_nan, sync_context, unwrap
 
 
 def joint_and_loss(model, loss_fn, args, f, f_lens, g, g_lens, txt, txt_lens, meta_data, loss_mods):
@@ -18,7 +18,11 @@ def joint_and_loss(model, loss_fn, args, f, f_lens, g, g_lens, txt, txt_lens, me
 
 
 def train_step_batch_split(model, loss_fn, args: Namespace, feats, feat_lens, txt, txt_lens, scaler, rnnt_state,
-                           loss_mods: LossModifiers) -> Tuple[float, bool, Optional[object]]:
+                           loss_mods: LossModifiers, final_backward: bool = True) -> Tuple[float, bool, Optional[object]]:
+    """The joint's parameters receive `batch_split_factor` gradient contributions per call, the encoder's and the
+    prediction network's one: under data parallelism the slice loop therefore only accumulates, and the joint's
+    gradients are declared final once it has run (the reference needs three DDP wrappers with static graphs for the
+    same reason, rnnt/sub_models.py:66-79)."""
     m = unwrap(model)
     k = args.batch_split_factor
     batch_size = len(feat_lens)
@@ -45,11 +49,16 @@ def train_step_batch_split(model, loss_fn, args: Namespace, feats, feat_lens, tx
                                   metas[i], loss_mods)
         if is_loss_nan(loss, getattr(args, "num_gpus", 1)):
             batch_has_nan = True
-        if scaler is not None:
-            scaler.scale(loss).backward()
-        else:
-            loss.backward()
+        with sync_context(model, False):
+            if scaler is not None:
+                scaler.scale(loss).backward()
+            else:
+                loss.backward()
         loss_item += loss.item()
-    f.backward(f_2.grad)
-    g.backward(g_2.grad)
+    reducer = getattr(m, "grad_reducer", None)
+    with sync_context(model, final_backward):
+        if reducer is not None and final_backward:
+            reducer.mark_ready(m.joint_net.parameters())
+        f.backward(f_2.grad)
+        g.backward(g_2.grad)
     return loss_item, batch_has_nan, None if batch_has_nan else new_state

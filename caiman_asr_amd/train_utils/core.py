@@ -2,6 +2,7 @@
 Mirror of training/caiman_asr_train/train_utils/core.py:20-88 and
 training/caiman_asr_train/rnnt/model_forward.py:19-101 (bf16 autocast instead of fp16 +
 GradScaler: bf16 needs no loss scaling)."""
+import contextlib
 from argparse import Namespace
 from typing import Optional, Tuple
 
@@ -46,10 +47,20 @@ def is_loss_nan(loss: torch.Tensor, num_gpus: int) -> bool:
     return bool(flag.item())
 
 
+def sync_context(model, final_backward: bool):
+    """Data-parallel runs exchange gradients ONCE per optimiser step (train_utils/distributed.py): every backward pass
+    but the last accumulates only.  With no reducer attached (single GPU) this is a no-op."""
+    reducer = getattr(unwrap(model), "grad_reducer", None)
+    if reducer is None or final_backward:
+        return contextlib.nullcontext()
+    return reducer.no_sync()
+
+
 def train_step(model, loss_fn, args: Namespace, feats, feat_lens, txt, txt_lens, scaler, rnnt_state,
-               loss_mods: LossModifiers) -> Tuple[float, bool, Optional[object]]:
-    """-> (loss value, loss_nan, new RNNTState|None).  `scaler` is accepted for signature parity
-    (fp16 GradScaler); with bf16 autocast it is None."""
+               loss_mods: LossModifiers, final_backward: bool = True) -> Tuple[float, bool, Optional[object]]:
+    """-> (loss value, loss_nan, new RNNTState|None).  `scaler`: a torch GradScaler under fp16 autocast
+    (`args.amp_dtype = torch.float16`), None under bf16 (the default) or `--no_amp`.  `final_backward` (an extra over
+    the reference signature): False for every micro-batch of a gradient-accumulation window except the last."""
     amp = not getattr(args, "no_amp", False)
     amp_dtype = getattr(args, "amp_dtype", torch.bfloat16)
     with torch.autocast("cuda", dtype=amp_dtype, enabled=amp):
@@ -57,8 +68,9 @@ def train_step(model, loss_fn, args: Namespace, feats, feat_lens, txt, txt_lens,
                                                    rnnt_state, loss_mods)
     loss_nan = is_loss_nan(loss, getattr(args, "num_gpus", 1))
     if not loss_nan:
-        if scaler is not None:
-            scaler.scale(loss).backward()
-        else:
-            loss.backward()
+        with sync_context(model, final_backward):
+            if scaler is not None:
+                scaler.scale(loss).backward()
+            else:
+                loss.backward()
     return loss.item(), loss_nan, new_state

@@ -18,6 +18,10 @@ _CHUNK = 1 << 16     # elements per workgroup chunk
 
 
 class FusedLAMB(torch.optim.Optimizer):
+    # torch.amp.GradScaler.step(): hand over `grad_scale` / `found_inf` instead of unscaling tensor by tensor and
+    # syncing on the host; step() divides the arena by the scale and caiman_lamb_step drops a non-finite step itself
+    _step_supports_amp_scaling = True
+
     def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
                  amsgrad=False, adam_w_mode=True, grad_averaging=True, set_grad_none=True, max_grad_norm=1.0,
                  use_nvlamb=False, ema_decay: Optional[float] = None):
@@ -91,6 +95,12 @@ class FusedLAMB(torch.optim.Optimizer):
     def last_step_applied(self) -> torch.Tensor:
         return self._work[2]
 
+    @property
+    def last_step_dropped_for_handoff(self) -> torch.Tensor:
+        """1 when the last step() was dropped because a weight-resident LSTM launch had timed out at a hand-off since
+        the step before (device scalar, no sync; include/caiman_rnnt.h, caiman_lamb_step)."""
+        return self._work[6]
+
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
 
@@ -123,6 +133,19 @@ class FusedLAMB(torch.optim.Optimizer):
     def step(self, closure=None, inv_grad_scale: float = 1.0, zero_grad: bool = False):
         import ctypes
 
+        # The decision to drop a step after a hand-off timeout is taken on the device (the host runs ahead of it);
+        # the host only reports it, once: the failure word is host memory, reading it costs nothing.
+        fails = int(_lib.lib().caiman_lstm_resident_failures())
+        if fails > getattr(self, "_handoff_failures_reported", 0):
+            import warnings
+
+            warnings.warn(f"{fails} hand-off timeout(s) in the weight-resident LSTM kernels: the optimiser drops the "
+                          "affected step(s) and the process stays on the per-timestep LSTM kernels "
+                          "(caiman_lstm_resident_set_failures(0) re-admits the resident ones)")
+        self._handoff_failures_reported = fails
+        grad_scale = getattr(self, "grad_scale", None)   # set by GradScaler.step() for the duration of the call
+        if grad_scale is not None:
+            self.flat_g.div_(grad_scale.to(self.flat_g.device))
         g0 = self.param_groups[0]
         n_groups = len(self.param_groups)
         lrs = (ctypes.c_float * n_groups)(*[float(g["lr"]) for g in self.param_groups])
@@ -150,3 +173,41 @@ def build_fused_lamb(args: Namespace, model, opt_eps: float) -> FusedLAMB:
 def build_optimizer(args: Namespace, model) -> FusedLAMB:
     """Top-level optimizer builder (eps = 1e-9, build_optimizer.py:27-32)."""
     return build_fused_lamb(args, model, 1e-9)
+
+
+class OptimizerWrapper:
+    """Optimiser + AMP scaling control of one training run (training/caiman_asr_train/train_utils/optimizer.py:11-57).
+
+    * bf16 autocast or `--no_amp` (scaler None): `step()` is the optimiser's; the inf / NaN test the reference makes
+      on the host (`np.isfinite(total_norm)`) is the device-side finite check of caiman_lamb_step.
+    * fp16 autocast (a torch GradScaler): `scaler.step(optimizer)`; FusedLAMB declares `_step_supports_amp_scaling`,
+      so the scaler hands it the loss scale and its found-inf flags without a host sync and the unscale is one
+      division of the gradient arena.  `lower_bound` keeps the scale from collapsing: when `update()` has taken it
+      below the bound, the next `update()` is told to set the bound instead (reference :38-47).
+    """
+
+    def __init__(self, args: Namespace, optimizer, scaler=None, lower_bound: Optional[float] = None, reducer=None):
+        self.args, self.optimizer, self.scaler, self.lower_bound = args, optimizer, scaler, lower_bound
+        self.reducer = reducer
+        self.scale = None   # override handed to the next scaler.update()
+
+    def zero_grad(self) -> None:
+        self.optimizer.zero_grad()
+
+    def step(self, total_norm: Optional[float] = None) -> None:
+        """`total_norm` is accepted for signature parity; the finite test runs on the device."""
+        if self.reducer is not None:
+            self.reducer.finish()          # data parallel: gradients become the mean over ranks first
+        if self.scaler is None:
+            self.optimizer.step()
+            return
+        self.scaler.step(self.optimizer)
+        self.scaler.update(self.scale)
+        self.scale = None
+        if self.lower_bound is not None and self.scaler.get_scale() < self.lower_bound:
+            print("WARNING: Overriding the grad scaler")
+            self.scale = self.lower_bound
+
+    @property
+    def learning_rate(self) -> float:
+        return self.optimizer.param_groups[0]["lr"]

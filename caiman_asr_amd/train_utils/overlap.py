@@ -1,21 +1,21 @@
-"""Side-stream execution of weight-gradient GEMMs.
+"""Hooks between the backward pass and the data-parallel gradient exchange.
 
-In the backward pass only the INPUT gradients are on the critical path; the weight gradients are needed just
-before the optimiser (or the all-reduce).  The LSTM backward that follows the joint's backward is a chain of
-latency-bound step kernels that leaves the matrix cores idle, so the big `dW = dYᵀ·X` GEMMs are launched on a
-second HIP stream and accumulate straight into the parameter's gradient (a view of the flat arena).
-`wait_all()` must be called before the gradients are consumed (reducer.finish() / optimizer.step()).
+* `register_grad_ready_callback`: LSTM stacks add their weight gradients straight into `param.grad` (views of the
+  optimiser's flat fp32 arena) instead of returning them to autograd, and tell the listeners (the reducer of
+  train_utils/distributed.py) per parameter, top layers first.
+* `fence_collectives`: the weight-resident LSTM kernels and a collective's kernel never share the chip.
+* `linear_transposed_backward`: the joint projection with its input gradient against a [K, N] weight copy.
+
+Round 1 also carried an opt-in side-stream path (weight-gradient GEMMs and the prediction network on second
+streams).  It was worth <= 1 % at batch 32 and its event graph could stall at batch >= 64: `flush_deferred()` made
+the side stream wait on a gate event recorded on the main stream while `wait_all()` / the reducer made the main and
+communication streams wait on the side stream, with thousands of per-timestep launches queued in between on the
+same hardware queue.  An opt-in path that can stall is worse than none: it has been removed.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 
-_side = {}
-_pending = False
-_deferred = []   # closures that launch side-stream work; run by flush_deferred()
-DEFER = os.environ.get("CAIMAN_DEFER", "1") != "0"   # hold the joint projection's weight-gradient GEMM back until the joint's own backward is queued
-_grad_ready_callbacks = []  # called as cb(param) right after a side-stream accumulation has been queued
+_grad_ready_callbacks = []  # called as cb(param) right after a direct accumulation into param.grad has been queued
 
 
 def register_grad_ready_callback(cb):
@@ -26,8 +26,9 @@ def clear_grad_ready_callbacks():
     _grad_ready_callbacks.clear()
 
 
-def side_streams():
-    return list(_side.values())
+def notify_grad_ready(param):
+    for cb in _grad_ready_callbacks:
+        cb(param)
 
 
 _comm_streams = []   # streams on which gradient collectives run (train_utils/distributed.py registers its own)
@@ -36,6 +37,11 @@ _comm_streams = []   # streams on which gradient collectives run (train_utils/di
 def register_comm_stream(stream):
     if stream is not None and stream not in _comm_streams:
         _comm_streams.append(stream)
+
+
+def unregister_comm_stream(stream):
+    if stream in _comm_streams:
+        _comm_streams.remove(stream)
 
 
 def fence_collectives():
@@ -49,95 +55,6 @@ def fence_collectives():
     cur = torch.cuda.current_stream()
     for s in _comm_streams:
         cur.wait_stream(s)
-
-
-def side_stream(device) -> torch.cuda.Stream:
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _side:
-        _side[key] = torch.cuda.Stream(device=device)
-    return _side[key]
-
-
-def flush_deferred():
-    """Launch side-stream work that was held back.  A long GEMM launched on the side stream the moment its inputs
-    exist fills every CU and starves the short kernel that comes next on the critical path (the joint's backward
-    reduction went from 0.4 ms to 3.7 ms); so the producer only files the launch, and the next stage of the backward
-    pass calls this right after queueing its own first kernel."""
-    global _deferred
-    if _deferred:
-        todo, _deferred = _deferred, []
-        # start behind what the caller has just queued, not next to it: the side streams wait for this point
-        gate = torch.cuda.Event()
-        gate.record(torch.cuda.current_stream())
-        for s in _side.values():
-            s.wait_event(gate)
-        for launch in todo:
-            launch()
-
-
-def wait_all():
-    """Make the current stream wait for every side-stream gradient GEMM issued so far."""
-    global _pending
-    flush_deferred()
-    if _pending:
-        for s in _side.values():
-            torch.cuda.current_stream().wait_stream(s)
-        _pending = False
-
-
-def _accumulate(param, value):
-    if param.grad is None:
-        param.grad = torch.zeros_like(param)
-    param.grad.add_(value.to(param.grad.dtype))
-    for cb in _grad_ready_callbacks:
-        cb(param)
-
-
-class _LinearOverlapped(torch.autograd.Function):
-    @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.bias = bias
-        return F.linear(x, weight, bias)
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, dy):
-        global _pending
-        x, weight = ctx.saved_tensors
-        bias = ctx.bias
-        dy = dy.contiguous()
-        dx = torch.matmul(dy, weight.to(dy.dtype)) if ctx.needs_input_grad[0] else None
-        main = torch.cuda.current_stream()
-        side = side_stream(dy.device)
-        ready = torch.cuda.Event()
-        ready.record(main)          # dy and x are complete here, whatever the main stream does afterwards
-
-        def launch():
-            global _pending
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                dy2 = dy.reshape(-1, dy.shape[-1])
-                x2 = x.reshape(-1, x.shape[-1]).to(dy.dtype)
-                _accumulate(weight, torch.matmul(dy2.t(), x2))
-                if bias is not None:
-                    _accumulate(bias, dy2.sum(0))
-            for t in (dy, x):
-                t.record_stream(side)
-            _pending = True
-
-        if DEFER:
-            _deferred.append(launch)
-        else:
-            launch()
-        return dx, None, None
-
-
-def linear_overlapped(x, weight, bias):
-    """F.linear whose weight / bias gradients are produced on the side stream and added to `.grad` directly
-    (autograd sees no gradient for them): call `wait_all()` before using the gradients."""
-    return _LinearOverlapped.apply(x, weight, bias)
 
 
 class _LinearTransposedBackward(torch.autograd.Function):

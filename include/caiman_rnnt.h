@@ -44,8 +44,9 @@ enum {
 
 typedef void* caiman_stream_t; /* hipStream_t */
 
-/* Library identity / diagnostics.  ABI version 3: slot structs of the wave calls carry `hidden` (2) and the backward
- * slot `dbias` (3); the resident-kernel controls were added with 3. */
+/* Library identity / diagnostics.  ABI version 4: slot structs of the wave calls carry `hidden` (2) and the backward
+ * slot `dbias` (3); the resident-kernel controls were added with 3; 4: caiman_lamb_step drops a step after a resident
+ * hand-off timeout (work[5], work[6]) and caiman_lstm_resident_poison carries that decision to the other ranks. */
 int caiman_abi_version(void);
 const char* caiman_last_error(void);
 /* 1 when the library was built with device code for gfx950. */
@@ -195,6 +196,11 @@ int caiman_lstm_resident_mode(int mode);
 int caiman_lstm_resident_failures(void);
 /* Overwrite the failure count (0 re-admits the resident kernels after an incident); returns the previous value. */
 int caiman_lstm_resident_set_failures(int count);
+/* Data-parallel agreement on a hand-off timeout: queued in front of the all-reduce of the gradient slice holding
+ * `grad_elem`, writes a NaN there when the failure count has moved past `*seen` (device word: work[5] of
+ * caiman_lamb_step's scratch, read as uint32), so that every rank's caiman_lamb_step drops the step.  No-op while
+ * no resident launch has been attempted on the device. */
+int caiman_lstm_resident_poison(float* grad_elem, const uint32_t* seen, caiman_stream_t stream);
 int64_t caiman_lstm_resident_launches(void);
 /* 1 when a multi-timestep wave call with n_slots slots of hidden size H and batch B would be one resident launch on
  * the current device (mode on, B <= 32, H/32 in {2,4,8,16,24,32}, n_slots * H/32 <= CUs). */
@@ -241,10 +247,13 @@ int caiman_joint_backward(const void* dh, const void* h_out, const int32_t* f_le
  *   (n_tensors + 1 entries), tensor_group[t].  These tables live on the DEVICE.
  * group_lr / group_wd : HOST arrays, n_groups <= 16 entries (passed by value to the kernels).
  * inv_grad_scale : 1/loss_scale (1 for bf16).  Non-finite gradient norm => p, m, v and the
- *   device step counter are left untouched (EMA still advances, as in the reference).
+ *   device step counter are left untouched (EMA still advances, as in the reference).  The same happens when a
+ *   weight-resident LSTM launch of this device has timed out at a hand-off since the previous call
+ *   (caiman_lstm_resident_failures moved): such a launch leaves stale but FINITE rows behind, so the decision is
+ *   taken on the device from the failure word itself; work[6] = 1 for a step dropped for that reason.
  * zero_grad : also clear g in the last pass (g otherwise holds the LAMB update on return).
  * work : device scratch of 8 + 2*n_chunks + n_tensors floats; work[0] = gradient norm,
- *        work[2] = 1 if the step was applied.
+ *        work[2] = 1 if the step was applied, work[5] (uint32) = failure count seen, work[6] as above.
  * ------------------------------------------------------------------------- */
 int caiman_lamb_step(float* p, float* g, float* m, float* v, float* ema,
                      const int64_t* chunk_start, const int32_t* chunk_len,

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "timeout(seconds): per-test limit (pytest-timeout; declared here so that the marker "
+                                       "is known when the plugin is absent)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -80,7 +80,96 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
+def _worker_protocol(rank, world, port, out):
+    """Batch splitting x gradient accumulation through the reducer's step protocol (no_sync / mark_ready / finish) on
+    a toy two-stage model: `enc` (one backward per micro-batch) feeding `joint` (one backward per slice).  The
+    exchanged gradients must equal the gradients of the concatenated global batch, bucket by bucket."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from caiman_asr_amd.train_utils.distributed import FlatGradReducer
+
+        torch.manual_seed(0)
+        enc, joint = torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)
+        params = list(enc.parameters()) + list(joint.parameters())
+        offsets, total = [], 0
+        for p in params:
+            offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        flat_g = torch.zeros(total)
+        for p, o in zip(params, offsets):
+            p.grad = flat_g[o:o + p.numel()].view(p.shape)
+        red = FlatGradReducer(params, offsets, flat_g, bucket_bytes=64 * 4, overlap=False)
+        assert len(red.buckets) >= 3
+        accum, split, per = 2, 2, 4                      # per rank: 2 micro-batches of 4 rows, joint in 2 slices
+        g = torch.Generator().manual_seed(5)
+        data = torch.randn(world, accum, per, 6, generator=g)
+
+        def loss_of(rows):
+            return joint(torch.tanh(enc(rows))).pow(2).sum(1)
+
+        # reference: the whole global batch at once, mean loss
+        flat_g.zero_()
+        with red.no_sync():
+            loss_of(data.reshape(-1, 6)).mean().backward()
+        ref = flat_g.clone()
+        flat_g.zero_()
+        for mb in range(accum):
+            final = mb == accum - 1
+            h = torch.tanh(enc(data[rank, mb]))
+            h2 = h.detach().requires_grad_(True)
+            for s in range(split):
+                with red.no_sync():                      # the joint is back-propagated slice by slice
+                    sl = slice(s * per // split, (s + 1) * per // split)
+                    (joint(h2[sl]).pow(2).sum(1).sum() / (per * accum)).backward()
+            if final:
+                red.mark_ready(joint.parameters())
+                h.backward(h2.grad)                      # hooks fire: enc's buckets go out as they complete
+            else:
+                with red.no_sync():
+                    h.backward(h2.grad)
+        red.finish()
+        assert torch.allclose(flat_g, ref, atol=1e-6), (flat_g - ref).abs().max()
+        # misuse: a second accumulation into a bucket whose collective is already in flight must raise
+        flat_g.zero_()
+        loss_of(data[rank, 0]).mean().backward()          # hooks on: every bucket is launched
+        try:
+            loss_of(data[rank, 1]).mean().backward()
+            raised = False
+        except RuntimeError as e:
+            raised = "no_sync" in str(e)
+        red.finish()
+        assert raised
+        out.put((rank, "ok", float(ref.abs().sum())))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        out.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run2(target):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, status, payload in res:
+        assert status == "ok", f"rank {rank}: {payload}"
+    return res
+
+
+def test_reducer_step_protocol_batch_split_and_accumulation_world2_gloo():
+    res = _run2(_worker_protocol)
+    assert res[0][2] == res[1][2]
+
+
 def test_flat_grad_reducer_world2_gloo():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()

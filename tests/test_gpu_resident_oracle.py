@@ -1,0 +1,128 @@
+"""GPU parity of the weight-resident LSTM chunk kernels (csrc/lstm.hip: lstm_fwd_resident / lstm_bwd_resident) DIRECTLY
+against the f64 CPU oracle (oracle/rnnt_oracle.c, a restatement of training/lib/csrc/lstm.cu:85-346), through the
+C-ABI wave calls the layer pipelines use.  The resident kernels are the default path of the benched configuration;
+tests/test_gpu_lstm.py compares them with the per-timestep kernels, this file anchors them to the oracle itself.
+
+Tolerance: inputs and every stored value are bf16 (8 significant bits, half-ulp 2^-9 relative).  One timestep adds a
+K-term fp32 dot product of bf16 operands (error ~ 2^-9 * sqrt(K) * |h| * |r| ~ 2^-9 since |r| ~ 1/sqrt(K)) and one
+rounding of each stored value; the recurrence is contractive (|f| < 1), so the drift over T steps stays a small
+multiple of the bf16 resolution.  Bounds below: max error <= 16 half-ulps of the value range, mean error <= 1 half-ulp.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16_HALF_ULP = 2.0 ** -9
+
+
+def _il(a, H):
+    """[..., 4H] gate-major (reference layout, lstm.cu:99-102) -> [..., H, 4] interleaved, flattened."""
+    return a.reshape(*a.shape[:-1], 4, H).transpose(-1, -2).reshape(a.shape)
+
+
+def _ref(a, H):
+    """inverse of _il."""
+    return a.reshape(*a.shape[:-1], H, 4).transpose(-1, -2).reshape(a.shape)
+
+
+def _resident_fwd_bwd(R, gates_ref, c0, y0, delta, hard, expect_resident=True):
+    """One LSTM layer, all T timesteps in ONE wave call each way (-> one resident launch).  Inputs: torch bf16 CPU
+    tensors in the reference layouts.  Returns (activated gates, c [T+1], y [T+1], dG) in the reference layouts."""
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    T, B, H4 = gates_ref.shape
+    H = H4 // 4
+    dt = torch.bfloat16
+    tag = _lib.dtype_tag(dt)
+    st = _lib.stream()
+    bp = (B + 31) // 32 * 32
+    Rd = R.to(DEV).contiguous()
+    G = _il(gates_ref, H).to(DEV).contiguous()
+    C = torch.zeros(T + 1, B, H, dtype=dt, device=DEV)
+    Y = torch.zeros(T + 1, B, H, dtype=dt, device=DEV)
+    C[0], Y[0] = c0.to(DEV), y0.to(DEV)
+    wt = torch.empty(4 * H * H, dtype=dt, device=DEV)
+    ring = torch.empty(2 * bp * H, dtype=dt, device=DEV)
+    n0 = lib.caiman_lstm_resident_launches()
+    _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rd), _lib.ptr(Y[0]), _lib.ptr(wt), _lib.ptr(ring), None, B, H, tag, 0, 1, st))
+    slot = _lib.FwdSlot(wt.data_ptr(), G.data_ptr(), C.data_ptr(), Y.data_ptr(), ring.data_ptr(), 0, T, None, 0, 0.0, 0)
+    arr = (_lib.FwdSlot * 1)(slot)
+    _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), 1, T, B, H, tag, int(hard), 1, 0, st))
+    # backward
+    D = delta.to(DEV).contiguous()
+    dG = torch.empty_like(G)
+    wtb = torch.empty(4 * H * H, dtype=dt, device=DEV)
+    ringb = torch.empty(2 * bp * 4 * H, dtype=dt, device=DEV)
+    dC = torch.empty(B * H, dtype=torch.float32, device=DEV)
+    dbias = torch.zeros(4 * H, dtype=torch.float32, device=DEV)
+    _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rd), None, _lib.ptr(wtb), _lib.ptr(ringb), _lib.ptr(dC), B, H, tag, 1, 1, st))
+    thi = T - 1
+    bslot = _lib.BwdSlot(wtb.data_ptr(), G[thi].data_ptr(), C[thi].data_ptr(), D[thi].data_ptr(), D.stride(0), D.stride(1),
+                         dG[thi].data_ptr(), ringb.data_ptr(), dC.data_ptr(), thi & 1, T, 0, 0.0, 0, 0, 0, dbias.data_ptr())
+    barr = (_lib.BwdSlot * 1)(bslot)
+    _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(barr, ctypes.c_void_p), 1, T, B, H, tag, int(hard), 1, 0, st))
+    torch.cuda.synchronize()
+    launches = lib.caiman_lstm_resident_launches() - n0
+    assert (launches == 2) == expect_resident, launches
+    assert lib.caiman_lstm_resident_failures() == 0
+    return (_ref(G.cpu(), H), C.cpu(), Y.cpu(), _ref(dG.cpu(), H), _ref(dbias.cpu(), H))
+
+
+@pytest.mark.parametrize("T,B,H", [(40, 32, 128), (40, 32, 1024), (33, 7, 256), (24, 32, 768)])
+@pytest.mark.parametrize("hard", [False, True])
+def test_resident_kernels_match_the_f64_oracle(T, B, H, hard):
+    from oracle import native
+
+    g = torch.Generator().manual_seed(1000 * T + H + int(hard))
+    dt = torch.bfloat16
+    R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dt)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    y0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    delta = torch.randn(T, B, H, generator=g).to(dt)
+    ga, c, y, dG, dbias = _resident_fwd_bwd(R, gates, c0, y0, delta, hard)
+    og, oc, oy = native.lstm_fwd(R.double().numpy(), gates.double().numpy(), c0.double().numpy(), y0.double().numpy(), hard=hard)
+
+    def check(name, got, ref, max_ulps, mean_ulps):
+        got = got.double().numpy()
+        scale = max(1.0, np.abs(ref).max())
+        err = np.abs(got - ref)
+        if hard:   # a clamp decided the other way on a rounded pre-activation moves a whole element: allow a few
+            assert np.mean(err > max_ulps * BF16_HALF_ULP * scale) < 2e-3, (name, err.max())
+        else:
+            assert err.max() <= max_ulps * BF16_HALF_ULP * scale, (name, err.max() / (BF16_HALF_ULP * scale))
+        assert err.mean() <= mean_ulps * BF16_HALF_ULP * scale, (name, err.mean() / (BF16_HALF_ULP * scale))
+
+    check("gates", ga, og, 16, 1.0)
+    check("y", y, oy, 16, 1.0)
+    check("c", c, oc, 32, 2.0)
+    # backward from the GPU's own (rounded) forward state, so that only the backward kernel is compared
+    odG, _ = native.lstm_bwd(R.double().numpy(), ga.double().numpy(), c.double().numpy(), delta.double().numpy(), hard=hard)
+    check("dG", dG, odG, 24, 1.5)
+    ob = odG.sum((0, 1))
+    assert np.allclose(dbias.double().numpy(), ob, atol=3e-2 * max(1.0, np.abs(ob).max())), "fused bias gradient"
+
+
+def test_resident_geometry_guard_keeps_other_shapes_on_the_step_kernels():
+    """B > 32 (until batch tiles are resident) must be served by the per-timestep kernels, with the same oracle bound."""
+    from oracle import native
+
+    T, B, H = 12, 40, 128
+    g = torch.Generator().manual_seed(5)
+    dt = torch.bfloat16
+    R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dt)
+    c0 = torch.zeros(B, H, dtype=dt)
+    y0 = torch.zeros(B, H, dtype=dt)
+    delta = torch.randn(T, B, H, generator=g).to(dt)
+    from caiman_asr_amd import _lib
+
+    would = bool(_lib.lib().caiman_lstm_resident_would_run(B, H, 1))
+    ga, c, y, dG, _ = _resident_fwd_bwd(R, gates, c0, y0, delta, False, expect_resident=would)
+    og, oc, oy = native.lstm_fwd(R.double().numpy(), gates.double().numpy(), c0.double().numpy(), y0.double().numpy())
+    assert np.abs(y.double().numpy() - oy).max() <= 16 * BF16_HALF_ULP

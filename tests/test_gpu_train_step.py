@@ -1,0 +1,342 @@
+"""GPU tests of the train-step surface around the kernels: optimiser-step gating on LSTM hand-off timeouts, fp16
+GradScaler path, gradient accumulation, random state passing through the layer-pipelined stacks, the base-85M model
+on BASELINE configs[0] against the CPU oracle, and the reference's own oracle-free pins (fp64 gradcheck of the loss
+and LSTM operators: training/lib/tests/transducer/test_loss.py:208-260, lib/tests/custom_lstm/test_cuda.py:12-42)."""
+import json
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def load(tag):
+    g = np.load(os.path.join(GOLD, f"rnnt_{tag}.npz"))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    return g, sd, json.loads(str(g["cfg"]))
+
+
+def build(tag, **over):
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    g, sd, cfg = load(tag)
+    cfg = dict(cfg, custom_lstm=True, **over)
+    m = RNNT(n_classes=int(g["n_classes"]), **cfg)
+    m.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    return g, sd, cfg, m.to(DEV)
+
+
+def _opt(m, ema=0.999):
+    from caiman_asr_amd.train_utils.optimizer import build_optimizer
+
+    return build_optimizer(Namespace(lr=4e-3, weight_decay=1e-2, beta1=0.9, beta2=0.999, clip_norm=1.0, ema=ema), m)
+
+
+def test_optimizer_drops_the_step_after_a_handoff_timeout():
+    """include/caiman_rnnt.h, caiman_lamb_step: a weight-resident LSTM launch that timed out at a hand-off leaves
+    stale FINITE rows behind, so the device-side finite check cannot catch it; the optimiser reads the failure word
+    itself and drops the step (reference: a bad step is dropped, not applied, train.py:274-284).  The timeout cannot be
+    provoked without wedging the GPU for seconds: the count is moved through the API, as the fallback test does."""
+    import warnings
+
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    lib.caiman_lstm_resident_would_run(8, 64, 1)   # creates the per-device resident state (and the failure word)
+    g, sd, cfg, m = build("tiny")
+    opt = _opt(m)
+
+    def fill():
+        for p in m.parameters():
+            p.grad.normal_()
+
+    fill()
+    opt.step()
+    assert opt.last_step_applied.item() == 1 and opt.last_step_dropped_for_handoff.item() == 0
+    before = [p.detach().clone() for p in m.parameters()]
+    step_before = int(opt._step.item())
+    prev = lib.caiman_lstm_resident_set_failures(3)
+    try:
+        fill()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            opt.step()
+        assert any("hand-off timeout" in str(x.message) for x in w)
+        assert opt.last_step_applied.item() == 0 and opt.last_step_dropped_for_handoff.item() == 1
+        assert int(opt._step.item()) == step_before
+        for p, b in zip(m.parameters(), before):
+            assert torch.equal(p, b)
+        # the count has not moved since: the next step (served by the per-timestep kernels) is applied again
+        fill()
+        opt.step()
+        assert opt.last_step_applied.item() == 1 and opt.last_step_dropped_for_handoff.item() == 0
+        assert not torch.equal(next(iter(m.parameters())), before[0])
+    finally:
+        lib.caiman_lstm_resident_set_failures(prev)
+    fill()
+    opt.step()      # clearing the count (re-admitting the resident kernels) must not drop a step
+    assert opt.last_step_applied.item() == 1
+
+
+def test_resident_poison_writes_nan_only_when_the_count_has_moved():
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    lib.caiman_lstm_resident_would_run(8, 64, 1)
+    grad = torch.ones(4, device=DEV)
+    seen = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.caiman_lstm_resident_poison(_lib.ptr(grad), _lib.ptr(seen), _lib.stream()))
+    assert torch.isfinite(grad).all()
+    prev = lib.caiman_lstm_resident_set_failures(prev_plus := 2)
+    try:
+        _lib.check(lib.caiman_lstm_resident_poison(_lib.ptr(grad), _lib.ptr(seen), _lib.stream()))
+        assert torch.isnan(grad[0]) and torch.isfinite(grad[1:]).all()
+        grad.fill_(1.0)
+        seen.fill_(prev_plus)
+        _lib.check(lib.caiman_lstm_resident_poison(_lib.ptr(grad), _lib.ptr(seen), _lib.stream()))
+        assert torch.isfinite(grad).all()
+    finally:
+        lib.caiman_lstm_resident_set_failures(prev)
+
+
+def test_fp16_grad_scaler_path_and_lower_bound():
+    """OptimizerWrapper with a torch GradScaler (reference train_utils/optimizer.py:31-48): finite step applied with
+    the unscaled gradient, an inf skips the step and halves the scale, the lower bound stops the collapse."""
+    from caiman_asr_amd.train_utils.optimizer import OptimizerWrapper
+
+    g, sd, cfg, m = build("tiny")
+    opt = _opt(m, ema=None)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=10 ** 6)
+    wrap = OptimizerWrapper(Namespace(no_amp=False), opt, scaler, lower_bound=512.0)
+    p0 = next(iter(m.parameters()))
+    ref = p0.detach().clone()
+    for p in m.parameters():
+        p.grad.fill_(1024.0 * 1e-3)       # scaled gradient of 1e-3
+    scaler._lazy_init_scale_growth_tracker(torch.device(DEV))
+    wrap.step()
+    assert opt.last_step_applied.item() == 1
+    total = sum(p.numel() for p in m.parameters())
+    assert opt.grad_norm.item() == pytest.approx(1e-3 * total ** 0.5, rel=1e-4)   # unscaled before the norm
+    assert not torch.equal(p0, ref)
+    ref = p0.detach().clone()
+    scales = []
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad.fill_(1.0)
+        p0.grad.view(-1)[0] = float("inf")
+        wrap.step()
+        assert opt.last_step_applied.item() == 0 and torch.equal(p0, ref)
+        scales.append(scaler.get_scale())
+    # 1024 -> 512 (backoff), -> 256 < bound: next update forced to 512, -> backoff again 256 -> forced ...
+    assert scales[0] == 512.0 and min(scales) >= 256.0 and wrap.scale in (None, 512.0)
+    assert scales[2] == 512.0 or scales[1] == 512.0
+
+
+def _batch(g, idx):
+    x = torch.tensor(g["x"][:, idx], device=DEV)
+    return x, torch.tensor(g["x_lens"][idx]), torch.tensor(g["y"][idx], device=DEV), torch.tensor(g["y_lens"][idx])
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_gradient_accumulation_equals_one_step_on_the_concatenated_batch(split):
+    """TrainStepper (train_utils/loop.py; reference train.py:215-300): two micro-batches of 2 utterances with
+    grad_accumulation_batches = 2 give the gradient of one step on the 4 utterances, with and without batch splitting."""
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers
+    from caiman_asr_amd.train_utils.core import train_step
+    from caiman_asr_amd.train_utils.loop import TrainStepper
+    from caiman_asr_amd.train_utils.optimizer import OptimizerWrapper
+    from caiman_asr_amd.train_utils.schedule import ConstantSchedule
+
+    idx = [0, 1, 2, 1]
+    g, sd, cfg, m = build("tiny", joint_apex_transducer="pack", joint_apex_relu_dropout=True)
+    m.train()
+    V = int(g["n_classes"])
+    loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+    args = Namespace(grad_accumulation_batches=1, batch_split_factor=1, no_amp=True, num_gpus=1)
+    mods = LossModifiers(delay_penalty=0.01, eos_penalty=0.0, star_penalty=1.0)
+    loss_ref, nan, _ = train_step(m, loss_fn, args, *_batch(g, idx), None, None, mods)
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    g, sd, cfg, m2 = build("tiny", joint_apex_transducer="pack", joint_apex_relu_dropout=True)
+    m2.train()
+    opt = _opt(m2)
+    captured = {}
+
+    class Capture(OptimizerWrapper):
+        def step(self, total_norm=None):
+            captured.update({n: p.grad.clone() for n, p in m2.named_parameters()})
+            super().step(total_norm)
+
+    args2 = Namespace(grad_accumulation_batches=2, batch_split_factor=split, no_amp=True, num_gpus=1)
+    stepper = TrainStepper(m2, loss_fn, args2, Capture(args2, opt), dp_scheduler=ConstantSchedule(0.01))
+    assert stepper.micro_batch(*_batch(g, idx[:2])) is None
+    rec = stepper.micro_batch(*_batch(g, idx[2:]))
+    assert rec is not None and rec["step"] == 1 and rec["loss"] == pytest.approx(loss_ref, rel=1e-5)
+    for n, gr in ref.items():
+        assert torch.allclose(captured[n], gr, rtol=1e-4, atol=1e-5), n
+    assert opt.last_step_applied.item() == 1
+
+
+def test_nan_loss_drops_the_accumulation_window():
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss
+    from caiman_asr_amd.train_utils.loop import TrainStepper
+    from caiman_asr_amd.train_utils.optimizer import OptimizerWrapper
+
+    g, sd, cfg, m = build("tiny", joint_apex_transducer="pack", joint_apex_relu_dropout=True)
+    m.train()
+    V = int(g["n_classes"])
+    loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+    args = Namespace(grad_accumulation_batches=2, batch_split_factor=1, no_amp=True, num_gpus=1)
+    opt = _opt(m)
+    stepper = TrainStepper(m, loss_fn, args, OptimizerWrapper(args, opt))
+    x, xl, y, yl = _batch(g, [0, 1])
+    assert stepper.micro_batch(x, xl, y, yl) is None and stepper.accumulated == 1
+    bad = x.clone()
+    bad[0, 0, 0] = float("nan")
+    assert stepper.micro_batch(bad, xl, y, yl) is None and stepper.accumulated == 0     # window restarts
+    assert stepper.micro_batch(x, xl, y, yl) is None
+    assert stepper.micro_batch(x, xl, y, yl)["step"] == 1
+
+
+@pytest.mark.parametrize("pipe", [True, False])
+def test_state_passing_through_the_pipelined_stacks_equals_the_concatenated_run(pipe):
+    """Random state passing (train_utils/rsp.py; reference rsp.py:17-205): running utterance halves A then B with the
+    state RNNT returned for A carried into B reproduces, for B, what the model computes on the concatenation A ++ B --
+    for the encoder (pre_rnn -> StackTime -> post_rnn as one layer pipeline, bf16 MFMA kernels, states entering as
+    row 0 of the [T+1, B, H] slabs) and for the prediction network (last token + next-to-last state)."""
+    from caiman_asr_amd.train_utils.rsp import rsp_end_step
+
+    g, sd, cfg, m = build("mfma", joint_apex_transducer="pack", joint_apex_relu_dropout=True)
+    m.train()
+    m.encoder_pipe = pipe
+    torch.manual_seed(0)
+    B, Ta, Tb, Ua, Ub = 4, 48, 40, 5, 6      # Ta even: StackTime pairs do not straddle the cut
+    V = int(g["n_classes"])
+    x = torch.randn(Ta + Tb, B, cfg["in_feats"], device=DEV)
+    y = torch.randint(0, V - 1, (B, Ua + Ub), device=DEV)
+    full_l = torch.full((B,), Ta + Tb, dtype=torch.int32, device=DEV)
+    a_l, b_l = torch.full_like(full_l, Ta), torch.full_like(full_l, Tb)
+    ya_l, yb_l = torch.full((B,), Ua, dtype=torch.int32, device=DEV), torch.full((B,), Ub, dtype=torch.int32, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        (f_full, _), (g_full, _), _ = m.enc_pred(x, full_l, y, ya_l + yb_l)
+        (f_a, _), (g_a, _), state = m.enc_pred(x[:Ta], a_l, y[:, :Ua], ya_l)
+        args = Namespace(rsp_seq_len_freq=[1, 1], rsp_delay=0)
+        carried, counter, active = rsp_end_step(state, False, 5, args, batches_until_history_reset=3)
+        assert active and carried is state and counter == 2
+        (f_b, _), (g_b, _), _ = m.enc_pred(x[Ta:], b_l, y[:, Ua:], yb_l, pred_net_state=carried.pred_net_state,
+                                           enc_state=carried.enc_state)
+    assert torch.equal(f_a, f_full[:, :Ta // 2])
+    # same kernels on the same bf16 values: the carried run is the concatenated run, bit for bit
+    assert torch.equal(f_b, f_full[:, Ta // 2:])
+    assert torch.equal(g_a, g_full[:, :Ua + 1])
+    # D of the reference's docstring: (last token, next-to-last state) + B's tokens == the tail of the concatenation
+    assert torch.equal(g_b[:, 1:], g_full[:, Ua + 1:])
+    # a NaN step or an exhausted history drops the state
+    assert rsp_end_step(state, True, 5, args, 3)[0] is None
+    assert rsp_end_step(state, False, 5, args, 1)[0] is None
+    assert rsp_end_step(state, False, 5, Namespace(rsp_seq_len_freq=[1, 1], rsp_delay=10), 3)[0] is None
+
+
+def test_base_85m_on_baseline_config0_matches_the_oracle():
+    """BASELINE.json configs[0]: base-85M, 2 synthetic 1 s utterances (feats [34, 2, 240], U = [5, 3]), forward + RNN-T
+    loss + backward: the HIP path in fp32 and under bf16 autocast against oracle.model.loss_and_grads (fp32 network,
+    f64 loss).  fp32 tolerance as stated in SURVEY section 8(d).1 (loss 1e-5 relative); bf16: storage resolution through
+    8 + 2 LSTM layers."""
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, get_packing_meta_data
+    from caiman_asr_amd.rnnt.model import RNNT
+    from oracle import model as omodel
+
+    cfg = json.load(open(os.path.join(GOLD, "rnnt_cfg_base.json")))
+    cfg = dict(cfg, enc_dropout=0.0, pred_dropout=0.0, joint_dropout=0.0)
+    V = 8704
+    torch.manual_seed(11)
+    m = RNNT(n_classes=V, **cfg).to(DEV)
+    m.train()
+    sd = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((34, 2, 240)).astype(np.float32)
+    x_lens = np.array([34, 30])
+    y = rng.integers(0, V - 1, size=(2, 5))
+    y_lens = np.array([5, 3])
+    ref_loss, ref_grads, _ = omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, V - 1, dtype=torch.float32)
+    names = ("joint_net.2.weight", "encoder.pre_rnn.lstm.weight_hh_l0", "encoder.post_rnn.lstm.weight_ih_l0",
+             "prediction.embed.weight")
+    xd, xl = torch.tensor(x, device=DEV), torch.tensor(x_lens)
+    yd, yl = torch.tensor(y, device=DEV), torch.tensor(y_lens)
+    meta = get_packing_meta_data(xl, yl, 2, device=DEV)
+    loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+    for amp, loss_tol, grad_tol in ((False, 1e-5, 2e-3), (True, 5e-3, 6e-2)):
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            logits, out_lens, _ = m(xd, xl.to(DEV), yd, yl.to(DEV), batch_offset=meta["batch_offset"],
+                                    packed_batch=meta["packed_batch"])
+            loss = loss_fn(logits, out_lens, yd, yl.to(DEV), meta["batch_offset"], meta["max_f_len"])
+        loss.backward()
+        assert abs(loss.item() - ref_loss) <= loss_tol * abs(ref_loss), (amp, loss.item(), ref_loss)
+        got = dict(m.named_parameters())
+        for n in names:
+            r = ref_grads[n]
+            err = np.abs(got[n].grad.double().cpu().numpy() - r).max() / (np.abs(r).max() + 1e-12)
+            assert err <= grad_tol, (amp, n, err)
+
+
+# ---- the reference's own oracle-free pins ---------------------------------------------------------------------------
+@pytest.mark.parametrize("batch_size,time_dim", [(1, 4), (2, 7), (8, 4)])
+@pytest.mark.parametrize("pack", [False, True])
+@pytest.mark.parametrize("eos_idx", [None, 1])
+@pytest.mark.parametrize("star_idx", [None, 2])
+def test_gradcheck_f64_transducer_loss(batch_size, time_dim, pack, eos_idx, star_idx):
+    """training/lib/tests/transducer/test_loss.py:208-260: torch.autograd.gradcheck of TransducerLossFunc in fp64 over
+    the reference's modifier grid (delay penalty x EOS penalty x star penalty; batch sizes / time dims / packing /
+    EOS / star labels as parameters).  Needs no oracle: the HIP backward against finite differences of the HIP forward."""
+    from caiman_asr_amd.rnnt_ext.transducer.loss import TransducerLossFunc
+    from tests.helpers import mock_lattice
+
+    d = mock_lattice(batch_size, time_dim, vocab=6, max_decode_length=4, seed=batch_size * 10 + time_dim, packed=pack,
+                     eos_idx=eos_idx, star_idx=star_idx)
+    label = torch.tensor(d["label"], device=DEV)
+    f_len, y_len = torch.tensor(d["f_len"], device=DEV), torch.tensor(d["y_len"], device=DEV)
+    bo = torch.tensor(d["batch_offset"], device=DEV) if pack else torch.empty(0)
+    grid = [(dp, ep, sp) for dp in (0.0, 0.05, 2.0) for ep in (0.0, 0.5) for sp in (0.0, 0.5)]
+    if eos_idx is None:
+        grid = [g_ for g_ in grid if g_[1] == 0.0]
+    if star_idx is None:
+        grid = [g_ for g_ in grid if g_[2] == 0.0]
+    for dp, ep, sp in grid:
+        x = torch.tensor(d["x"], dtype=torch.float64, device=DEV, requires_grad=True)
+
+        def stub(inp):
+            return TransducerLossFunc.apply(inp, label, f_len, y_len, bo, dp, d["max_f_len"], d["blank"], ep, eos_idx, sp,
+                                            star_idx, None, pack)
+
+        assert torch.autograd.gradcheck(stub, [x]), (dp, ep, sp)
+
+
+@pytest.mark.parametrize("seq_length,batch_size,input_size,hidden_size", [(1, 1, 1, 1), (7, 3, 2, 5), (7, 1, 1, 5), (1, 3, 2, 1)])
+@pytest.mark.parametrize("hard", [False, True])
+def test_gradcheck_f64_lstm_layer(seq_length, batch_size, input_size, hidden_size, hard):
+    """training/lib/tests/custom_lstm/test_cuda.py:12-42: fp64 gradcheck of the fused LSTM layer function, soft and hard
+    activations, with respect to X, W, R and both biases."""
+    import caiman_asr_amd.rnnt_ext.custom_lstm.lstm as L
+
+    torch.manual_seed(seq_length * 100 + hidden_size * 10 + int(hard))
+    kw = dict(dtype=torch.float64, device=DEV, requires_grad=True)
+    layer = L.HardLayer() if hard else L.SoftLayer()
+    X = torch.randn(seq_length, batch_size, input_size, **kw)
+    h0 = torch.randn(batch_size, hidden_size, dtype=torch.float64, device=DEV)
+    c0 = torch.randn(batch_size, hidden_size, dtype=torch.float64, device=DEV)
+    R = torch.randn(4 * hidden_size, hidden_size, **kw)
+    W = torch.randn(4 * hidden_size, input_size, **kw)
+    BW = torch.randn(4 * hidden_size, **kw)
+    BR = torch.randn(4 * hidden_size, **kw)
+
+    def stub(X, W, R, BW, BR):
+        out, *_ = layer(h0, c0, X, W, R, BW, BR)
+        return out
+
+    assert torch.autograd.gradcheck(stub, [X, W, R, BW, BR])

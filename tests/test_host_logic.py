@@ -189,3 +189,106 @@ def test_encoder_pipeline_schedule_respects_dependencies():
                     for c in range(lo // CH, -(-hi // CH)):
                         assert when[(La - 1, c)] < t
     ep.FINE = True
+
+
+# ---- train-step control pieces (round 2): schedules, RSP controller, optimiser wrapper ------------------------------
+def test_step_schedule_latches_on_step_or_wer():
+    # training/caiman_asr_train/train_utils/schedule.py:57-114; wiring setup/train.py:212-229
+    from argparse import Namespace
+
+    from caiman_asr_amd.train_utils.schedule import (ConstantSchedule, StepSchedule, build_delay_penalty_scheduler,
+                                                     build_star_scheduler)
+
+    s = StepSchedule(0.75, 1.0, wer_threshold=0.2)
+    assert s.value() == 0.75 and s.step(10, hints={"wer": 0.5}) == 0.75
+    assert s.step(11, hints={"wer": 0.19}) == 1.0
+    assert s.step(12, hints={"wer": 0.9}) == 1.0          # latched
+    with pytest.raises(ValueError):
+        StepSchedule(0.0, 1.0)
+    with pytest.raises(ValueError):
+        StepSchedule(0.0, 1.0, wer_threshold=0.3).step(1)   # WER expected in hints
+    t = StepSchedule(0.0, 0.01, toggle_step=100, wer_threshold=0.3)
+    assert t.step(99) == 0.0 and t.step(100) == 0.01
+    assert ConstantSchedule(0.3).step(5) == 0.3
+    dp = build_delay_penalty_scheduler(Namespace(delay_penalty="wer_schedule", dp_initial_value=0.0, dp_final_value=0.01,
+                                                 dp_toggle_step=None, dp_wer_threshold=0.3))
+    assert dp.step(1, hints={"wer": 1.0}) == 0.0 and dp.step(2, hints={"wer": 0.29}) == 0.01
+    assert build_delay_penalty_scheduler(Namespace(delay_penalty="0.005")).value() == 0.005
+    star = build_star_scheduler(Namespace())
+    assert star.value() == 0.75 and star.step(3, hints={"wer": 0.1}) == 1.0
+
+
+def test_rsp_controller():
+    # training/caiman_asr_train/train_utils/rsp.py:17-104; statistics as training/tests/train_utils/test_rsp.py
+    import random
+    from argparse import Namespace
+
+    from caiman_asr_amd.train_utils import rsp
+
+    assert not rsp.is_random_state_passing_on([1]) and not rsp.is_random_state_passing_on([3, 0, 0])
+    assert rsp.is_random_state_passing_on([10, 0, 1])
+    random.seed(0)
+    trials = 10 ** 4
+    draws = [rsp.generate_batch_history([10, 0, 2]) for _ in range(trials)]
+    assert set(draws) == {1, 3} and draws.count(1) / trials == pytest.approx(10 / 12, abs=0.015)
+    args = Namespace(rsp_delay=None, warmup_steps=1632, hold_steps=18000, half_life_steps=10880, training_steps=10 ** 5,
+                     rsp_seq_len_freq=[99, 0, 1])
+    cfg = {"rnnt": {"custom_lstm": True, "enc_batch_norm": False, "pred_batch_norm": False}}
+    rsp.rsp_config_checks(args, cfg)
+    assert args.rsp_delay == 1632 + 18000 + 3 * 10880
+    with pytest.raises(AssertionError):
+        rsp.rsp_config_checks(Namespace(rsp_seq_len_freq=[1, 1], rsp_delay=0), {"rnnt": dict(cfg["rnnt"], custom_lstm=False)})
+    with pytest.raises(AssertionError):
+        rsp.rsp_config_checks(Namespace(rsp_seq_len_freq=[0, 0], rsp_delay=0), cfg)
+    state = object.__new__(rsp.RNNTState)
+    a = Namespace(rsp_seq_len_freq=[1, 1], rsp_delay=100)
+    assert rsp.rsp_end_step(state, False, 99, a, 5) == (None, 4, False)          # before the delay
+    assert rsp.rsp_end_step(state, False, 100, a, 5) == (state, 4, True)
+    assert rsp.rsp_end_step(state, True, 100, a, 5)[0] is None                    # NaN: the state may be the cause
+    carry, counter, on = rsp.rsp_end_step(state, False, 100, a, 1)               # history used up: reset + redraw
+    assert carry is None and counter in (1, 2) and on
+    off = Namespace(rsp_seq_len_freq=[1], rsp_delay=0)
+    assert rsp.rsp_end_step(None, False, 5, off, 1) == (None, 1, False)
+
+
+def test_optimizer_wrapper_lower_bound_logic():
+    # training/caiman_asr_train/train_utils/optimizer.py:31-48 with a scripted scaler
+    from argparse import Namespace
+
+    from caiman_asr_amd.train_utils.optimizer import OptimizerWrapper
+
+    class FakeScaler:
+        def __init__(self):
+            self.scale, self.updates, self.steps = 1024.0, [], 0
+
+        def step(self, opt):
+            self.steps += 1
+
+        def update(self, new=None):
+            self.updates.append(new)
+            self.scale = new if new is not None else self.scale / 2
+
+        def get_scale(self):
+            return self.scale
+
+    class FakeOpt:
+        param_groups = [{"lr": 0.5}]
+        n = 0
+
+        def step(self):
+            FakeOpt.n += 1
+
+        def zero_grad(self):
+            pass
+
+    sc = FakeScaler()
+    w = OptimizerWrapper(Namespace(no_amp=False), FakeOpt(), sc, lower_bound=300.0)
+    w.step()          # 512
+    w.step()          # 256 < 300 -> override queued
+    assert w.scale == 300.0
+    w.step()          # update(300)
+    assert sc.updates == [None, None, 300.0] and sc.scale == 300.0 and w.scale is None and sc.steps == 3
+    assert w.learning_rate == 0.5
+    plain = OptimizerWrapper(Namespace(no_amp=True), FakeOpt(), None)
+    plain.step()
+    assert FakeOpt.n == 1
