@@ -113,6 +113,9 @@ _SIGS = {
     "caiman_transducer_loss_backward": (
         [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
          P, P], ctypes.c_int),
+    "caiman_transducer_loss_backward_colsum": (
+        [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
+         P, P, I64, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_lstm_workspace_elems": ([I64, I64, I32], ctypes.c_int64),
     "caiman_lstm_prepare": ([P, P, P, P, P, I64, I64, I32, I32, I32, P], ctypes.c_int),

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T* __restrict__ f,
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   auto one = [&](float a, float c, int64_t h) -> float {
     float v = a + c;
-    if (relu) v = v > 0.f ? v : 0.f;
+    // NaN-propagating like torch.relu (the reference's CPU joint, model.py:441-447): a non-finite encoder / prediction
+    // output must reach the loss as NaN so that the batch is dropped (core.py:20-42), not be clamped to 0 here
+    if (relu) v = (v > 0.f || v != v) ? v : 0.f;
     if (drop_p > 0.f) v = (uniform_from(seed, (uint64_t)(row * s.H + h)) < drop_p) ? 0.f : v * keep_scale;
     return v;
   };

@@ -360,6 +360,220 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
   for (int64_t h = nfull * VEC + lane; h < p.V; h += kWave) gx[h] = static_cast<T>(one(static_cast<A>(rx[h]), h));
 }
 
+// ---------------------------------------------------------------------------
+// backward + column sums of the gradient: the bias gradient of the projection that produced x, which the reference
+// obtains from a separate pass over the whole gradient (autograd's grad_output.sum(0) for joint_fc.bias; 5.3 GB /
+// 0.93 ms per step at B = 32).
+//   1. loss_row_desc_kernel: one thread per row reduces everything that is constant along a row (utterance lookup,
+//      lattice scalars, penalties, label / blank / star rules) to a 32-byte descriptor: the gradient of an element is
+//      exp(x + base) - [up rule](exp(x + up_off)) - [right rule](exp(x + right_off)).
+//   2. loss_bwd_colsum_kernel: a workgroup of 4 waves takes `rows_per_block` consecutive rows; each wave owns a quarter
+//      of the 16-byte column chunks and walks all of the workgroup's rows on its own (no barriers), so a lane meets the
+//      same <= KACC chunks in every row and keeps their sums in registers (40 floats at V = 8704).  One partial row [V]
+//      per workgroup is left for the caller to add up, in a fixed order.
+// Tried first: one wave per row summing into an LDS array with ds_add_f32 (7x slower: 16-way bank conflicts on top of
+// the atomic rate); then the per-row scalar code of the plain kernel inside the column-quarter loop (226 VGPRs, two
+// waves per SIMD, a full vmcnt(0) drain per row: 2.2x slower than the plain kernel).  The sums are taken over the values
+// as rounded to T, as the separate pass would see them.
+// ---------------------------------------------------------------------------
+template <typename A>
+struct alignas(32) RowDesc {
+  A base, up_off, right_off;
+  int32_t lab_up;       // -1: no "up" term, -2: every column (star), else the label column
+  int32_t right_mode;   // 0: no "right" term, 1: blank column only, 2: every column (star), 3: don't-care row (zeros)
+};
+static_assert(sizeof(RowDesc<float>) == 32 && sizeof(RowDesc<double>) == 32, "descriptor size");
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_row_desc_kernel(const acc_t<T>* __restrict__ denom,
+                                                            const acc_t<T>* __restrict__ loss_grad,
+                                                            const acc_t<T>* __restrict__ alpha,
+                                                            const acc_t<T>* __restrict__ beta, LossParams p,
+                                                            int64_t total_rows, RowDesc<acc_t<T>>* __restrict__ desc) {
+  using A = acc_t<T>;
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= total_rows) return;
+  int b;
+  int64_t local, Un_stride;
+  if (p.packed) {
+    int lo = 0, hi = p.batch - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (p.batch_offset[mid] > row) hi = mid; else lo = mid + 1;
+    }
+    b = lo;
+    local = row - (b == 0 ? 0 : p.batch_offset[b - 1]);
+    Un_stride = p.y_len[b] + 1;
+  } else {
+    const int64_t per = p.max_flen * p.max_glen;
+    b = (int)(row / per);
+    local = row - (int64_t)b * per;
+    Un_stride = p.max_glen;
+  }
+  const int64_t Tn = p.f_len[b];
+  const int64_t Un = p.y_len[b] + 1;
+  const int64_t t = local / Un_stride;
+  const int64_t u = local - t * Un_stride;
+  RowDesc<A> d;
+  d.base = d.up_off = d.right_off = (A)0;
+  d.lab_up = -1;
+  d.right_mode = 3;
+  if (t < Tn && u < Un) {
+    // same arithmetic, in the same order, as loss_bwd_kernel (transducer_loss.cu:297-387)
+    const A* my_alpha = alpha + (int64_t)b * p.max_flen * p.max_glen;
+    const A* my_beta = beta + (int64_t)b * p.max_flen * p.max_glen;
+    const int32_t* lab = p.label + (int64_t)b * (p.max_glen - 1);
+    const A dp_lam = (A)p.dp_lam, eos_lam = (A)p.eos_lam, star_lam = (A)p.star_lam;
+    const A Tf = (A)Tn;
+    const A den = denom[row];
+    const A common = log(loss_grad[b]) + my_alpha[t * p.max_glen + u] - my_beta[0];
+    const A beta_TU = my_beta[t * p.max_glen + u];
+    const int32_t labU = (u == 0) ? -1 : lab[u - 1];
+    const bool not_top = (u != Un - 1);
+    const bool last_t = (t == Tn - 1);
+    A beta_TUp1 = 0, beta_Tp1U = 0;
+    int32_t labUp1 = -4;
+    if (!last_t) beta_Tp1U = my_beta[(t + 1) * p.max_glen + u];
+    if (not_top) {
+      beta_TUp1 = my_beta[t * p.max_glen + u + 1] + frac_penalty<A>(dp_lam, (A)t, Tf);
+      labUp1 = lab[u];
+      if (labUp1 == p.eos_idx) beta_TUp1 += frac_penalty<A>(eos_lam, (A)t, Tf);
+    }
+    const bool up_all = not_top && (labUp1 == p.star_idx);
+    const bool right_all = (labU == p.star_idx);
+    const A star_pen = right_all ? star_lam : (A)0;
+    const bool right_term = last_t && !not_top;
+    const bool right_any = right_term || !last_t;
+    const A right_add = right_term ? star_pen : beta_Tp1U + star_pen;
+    const A nan = static_cast<A>(NAN);
+    const bool den_ok = isfinite(den);
+    d.base = den_ok ? common + beta_TU - den : nan;          // a non-finite normaliser makes the whole row NaN
+    d.up_off = common - den + beta_TUp1;
+    d.right_off = common - den + right_add;
+    d.lab_up = !not_top ? -1 : (up_all ? -2 : labUp1);
+    d.right_mode = !right_any ? 0 : (right_all ? 2 : 1);
+  }
+  desc[row] = d;
+}
+
+template <typename T, int VEC, int KACC>
+__global__ __launch_bounds__(256) void loss_bwd_colsum_kernel(const T* __restrict__ x,
+                                                              const RowDesc<acc_t<T>>* __restrict__ desc, int64_t V,
+                                                              int64_t blank, int64_t total_rows, T* __restrict__ x_grad,
+                                                              int rows_per_block, float* __restrict__ colsum_partial) {
+  using A = acc_t<T>;
+  using Vt = vecT<T, VEC>;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave, nwave = blockDim.x / kWave;
+  // 32-bit column arithmetic throughout (V < 2^31): 64-bit per-element invariants cost dozens of VGPRs
+  const int nchunk = (int)(V / VEC);                   // the launch guarantees V % VEC == 0
+  const int quarter = (nchunk + nwave - 1) / nwave;    // and KACC * 64 >= quarter
+  const int cbeg = wave * quarter;
+  const int cend = cbeg + quarter < nchunk ? cbeg + quarter : nchunk;
+  const int blank_col = (int)blank;
+  const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row_end = row_begin + rows_per_block < total_rows ? row_begin + rows_per_block : total_rows;
+  float acc[KACC][VEC];
+#pragma unroll
+  for (int k = 0; k < KACC; ++k)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[k][j] = 0.f;
+  auto fexp = [](A v) -> A {
+    if constexpr (sizeof(T) == 2) return __expf(v);
+    else return exp(v);
+  };
+  const int c0 = cbeg + lane;
+  for (int64_t row = row_begin; row < row_end; ++row) {
+    const RowDesc<A> d = desc[row];     // wave-uniform
+    const T* rx = x + row * V + (int64_t)c0 * VEC;
+    T* gx = x_grad + row * V + (int64_t)c0 * VEC;
+    if (d.right_mode == 3) {   // padded layout: zero the don't-care region (transducer_loss.cu:388-393)
+      Vt z;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) z.v[j] = static_cast<T>(0);
+#pragma unroll
+      for (int k = 0; k < KACC; ++k)
+        if (c0 + k * kWave < cend) *reinterpret_cast<Vt*>(gx + (int64_t)k * kWave * VEC) = z;
+      continue;
+    }
+    Vt v[KACC];
+#pragma unroll
+    for (int k = 0; k < KACC; ++k) {
+      if (c0 + k * kWave < cend) {
+        if constexpr (sizeof(Vt) == 16) {
+          using u4 = __attribute__((ext_vector_type(4))) unsigned;
+          const u4 raw = __builtin_nontemporal_load(reinterpret_cast<const u4*>(rx + (int64_t)k * kWave * VEC));
+          __builtin_memcpy(&v[k], &raw, 16);
+        } else {
+          v[k] = *reinterpret_cast<const Vt*>(rx + (int64_t)k * kWave * VEC);
+        }
+      }
+    }
+    const bool up_any = d.lab_up != -1, up_all = d.lab_up == -2;
+    const bool right_any = d.right_mode != 0, right_all = d.right_mode == 2;
+#pragma unroll
+    for (int k = 0; k < KACC; ++k) {
+      if (c0 + k * kWave < cend) {
+        // Every element takes exp(x + base); the second / third term touches ONE column of the row (the label, the
+        // blank) unless the row is a star row.  Whether that column lies in the 64 chunks this wave-instruction covers
+        // is wave-uniform: a scalar branch around a block of selects, instead of per-element control flow.
+        const int w0 = (cbeg + k * kWave) * VEC, w1 = w0 + kWave * VEC;   // columns of chunk row k
+        // element j of this lane's chunk is column h0 + j: compare j with (column - h0), one 32-bit value per lane
+        // (64-bit column numbers for all KACC x VEC elements cost 80 VGPRs as loop invariants)
+        const int h0 = (c0 + k * kWave) * VEC;
+        const int rel_up = d.lab_up - h0, rel_blank = blank_col - h0;
+        A g[VEC], xv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          xv[j] = static_cast<A>(v[k].v[j]);
+          g[j] = fexp(xv[j] + d.base);
+        }
+        if (up_any && (up_all || (d.lab_up >= w0 && d.lab_up < w1))) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const A e = fexp(xv[j] + d.up_off);
+            g[j] -= (up_all || rel_up == j) ? e : (A)0;
+          }
+        }
+        if (right_any && (right_all || (blank_col >= w0 && blank_col < w1))) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const A e = fexp(xv[j] + d.right_off);
+            g[j] -= (right_all || rel_blank == j) ? e : (A)0;
+          }
+        }
+        Vt o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          o.v[j] = static_cast<T>(g[j]);
+          acc[k][j] += static_cast<float>(o.v[j]);
+        }
+        if constexpr (sizeof(Vt) == 16) {
+          using u4 = __attribute__((ext_vector_type(4))) unsigned;
+          u4 raw;
+          __builtin_memcpy(&raw, &o, 16);
+          __builtin_nontemporal_store(raw, reinterpret_cast<u4*>(gx + (int64_t)k * kWave * VEC));
+        } else {
+          *reinterpret_cast<Vt*>(gx + (int64_t)k * kWave * VEC) = o;
+        }
+      }
+      // one chunk at a time: left to itself the scheduler interleaves the exps of all KACC chunks (251 VGPRs, one
+      // wave per SIMD at KACC = 5)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (row_begin < row_end) {
+    float* out = colsum_partial + (int64_t)blockIdx.x * V + (int64_t)c0 * VEC;
+#pragma unroll
+    for (int k = 0; k < KACC; ++k) {
+      if (c0 + k * kWave < cend) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) out[(int64_t)k * kWave * VEC + j] = acc[k][j];
+      }
+    }
+  }
+}
+
 int check_common(int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t V, int64_t blank,
                  int64_t eos_idx, int64_t star_idx) {
   CAIMAN_CHECK(batch >= 1 && max_f_len >= 1 && max_g_len >= 1 && V >= 1, "transducer_loss: bad extents");
@@ -402,13 +616,14 @@ extern "C" int caiman_transducer_loss_forward(
   });
 }
 
-extern "C" int caiman_transducer_loss_backward(
-    const void* x, const void* denom, const void* loss_grad, const void* alpha, const void* beta,
-    const int32_t* f_len, const int32_t* y_len, const int32_t* label, const int64_t* batch_offset,
-    int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t dict_size, int64_t total_rows,
-    double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx, double star_lam, int64_t star_idx,
-    int packed, int dtype, void* x_grad, caiman_stream_t stream) {
-  using namespace caiman;
+namespace caiman {
+namespace {
+int loss_backward_impl(const void* x, const void* denom, const void* loss_grad, const void* alpha, const void* beta,
+                       const int32_t* f_len, const int32_t* y_len, const int32_t* label, const int64_t* batch_offset,
+                       int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t dict_size, int64_t total_rows,
+                       double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx, double star_lam, int64_t star_idx,
+                       int packed, int dtype, void* x_grad, float* colsum_partial, int64_t rows_per_block,
+                       caiman_stream_t stream) {
   if (int e = check_common(batch, max_f_len, max_g_len, dict_size, blank_idx, eos_idx, star_idx)) return e;
   CAIMAN_CHECK(x && denom && loss_grad && alpha && beta && label && f_len && y_len && x_grad,
                "transducer_loss_backward: null pointer");
@@ -417,12 +632,13 @@ extern "C" int caiman_transducer_loss_backward(
   CAIMAN_CHECK(packed || total_rows == batch * max_f_len * max_g_len,
                "transducer_loss_backward: padded input must have B*T*U rows");
   CAIMAN_CHECK(batch <= 65535, "transducer_loss_backward: batch too large for one launch");
+  CAIMAN_CHECK(rows_per_block >= 4 && rows_per_block % 4 == 0 && rows_per_block <= 4096,
+               "transducer_loss_backward: rows_per_block must be a multiple of 4 in [4, 4096]");
   if (total_rows == 0) return CAIMAN_OK;
   LossParams p{label, f_len, y_len, batch_offset, max_f_len, max_g_len, dict_size, blank_idx,
                eos_idx, star_idx, dp_lam, eos_lam, star_lam, packed, (int)batch};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  constexpr int kRowsPerBlock = 4;
-  const int64_t nblk = (total_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int64_t nblk = (total_rows + rows_per_block - 1) / rows_per_block;
   CAIMAN_CHECK(nblk < ((int64_t)1 << 31), "transducer_loss_backward: too many rows for one launch");
   return CAIMAN_DISPATCH(dtype, "transducer_loss_backward", [&]() -> int {
     using A = acc_t<scalar_t>;
@@ -433,15 +649,59 @@ extern "C" int caiman_transducer_loss_backward(
     const dim3 grid((unsigned)nblk);
     auto xs = static_cast<const scalar_t*>(x);
     auto gs = static_cast<scalar_t*>(x_grad);
-    if (aligned) {
-      hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, VEC>), grid, dim3(256), 0, s, xs,
-                         static_cast<const A*>(denom), static_cast<const A*>(loss_grad),
-                         static_cast<const A*>(alpha), static_cast<const A*>(beta), p, total_rows, gs);
+    using AA = const A*;
+    if (colsum_partial) {
+      // a lane keeps the sums of its column chunks in registers: chunks per lane = ceil(ceil(V / VEC / 4 waves) / 64 lanes)
+      CAIMAN_CHECK(aligned, "transducer_loss_backward_colsum: x, x_grad and the rows must be 16-byte aligned");
+      const int64_t per_lane = ((dict_size / VEC + 3) / 4 + kWave - 1) / kWave;
+      CAIMAN_CHECK(per_lane <= 16, "transducer_loss_backward_colsum: dict_size %lld too large for the fused column sums",
+                   (long long)dict_size);
+      // descriptors behind the partial sums: [nblk, V] floats (rounded up to a multiple of 8), then total_rows * 32 bytes
+      const int64_t lead = (nblk * dict_size + 7) / 8 * 8;
+      auto* desc = reinterpret_cast<RowDesc<A>*>(colsum_partial + lead);
+      CAIMAN_CHECK(reinterpret_cast<uintptr_t>(desc) % 32 == 0, "transducer_loss_backward_colsum: workspace must be 32-byte aligned");
+      hipLaunchKernelGGL((loss_row_desc_kernel<scalar_t>), dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, s,
+                         (AA)denom, (AA)loss_grad, (AA)alpha, (AA)beta, p, total_rows, desc);
+      auto go = [&](auto k_tag) {
+        constexpr int K_ = decltype(k_tag)::value;
+        hipLaunchKernelGGL((loss_bwd_colsum_kernel<scalar_t, VEC, K_>), grid, dim3(256), 0, s, xs, desc, dict_size, blank_idx,
+                           total_rows, gs, (int)rows_per_block, colsum_partial);
+      };
+      if (per_lane <= 5) go(std::integral_constant<int, 5>{});
+      else if (per_lane <= 9) go(std::integral_constant<int, 9>{});
+      else go(std::integral_constant<int, 16>{});
+    } else if (aligned) {
+      hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, VEC>), grid, dim3(256), 0, s, xs, (AA)denom, (AA)loss_grad, (AA)alpha,
+                         (AA)beta, p, total_rows, gs);
     } else {
-      hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, 1>), grid, dim3(256), 0, s, xs,
-                         static_cast<const A*>(denom), static_cast<const A*>(loss_grad),
-                         static_cast<const A*>(alpha), static_cast<const A*>(beta), p, total_rows, gs);
+      hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, 1>), grid, dim3(256), 0, s, xs, (AA)denom, (AA)loss_grad, (AA)alpha,
+                         (AA)beta, p, total_rows, gs);
     }
     return check_launch("caiman_transducer_loss_backward");
   });
+}
+}  // namespace
+}  // namespace caiman
+
+extern "C" int caiman_transducer_loss_backward(
+    const void* x, const void* denom, const void* loss_grad, const void* alpha, const void* beta,
+    const int32_t* f_len, const int32_t* y_len, const int32_t* label, const int64_t* batch_offset,
+    int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t dict_size, int64_t total_rows,
+    double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx, double star_lam, int64_t star_idx,
+    int packed, int dtype, void* x_grad, caiman_stream_t stream) {
+  return caiman::loss_backward_impl(x, denom, loss_grad, alpha, beta, f_len, y_len, label, batch_offset, batch, max_f_len,
+                                    max_g_len, dict_size, total_rows, dp_lam, blank_idx, eos_lam, eos_idx, star_lam,
+                                    star_idx, packed, dtype, x_grad, nullptr, 4, stream);
+}
+
+extern "C" int caiman_transducer_loss_backward_colsum(
+    const void* x, const void* denom, const void* loss_grad, const void* alpha, const void* beta,
+    const int32_t* f_len, const int32_t* y_len, const int32_t* label, const int64_t* batch_offset,
+    int64_t batch, int64_t max_f_len, int64_t max_g_len, int64_t dict_size, int64_t total_rows,
+    double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx, double star_lam, int64_t star_idx,
+    int packed, int dtype, void* x_grad, float* colsum_partial, int64_t rows_per_block, caiman_stream_t stream) {
+  CAIMAN_CHECK(colsum_partial, "transducer_loss_backward_colsum: null colsum_partial");
+  return caiman::loss_backward_impl(x, denom, loss_grad, alpha, beta, f_len, y_len, label, batch_offset, batch, max_f_len,
+                                    max_g_len, dict_size, total_rows, dp_lam, blank_idx, eos_lam, eos_idx, star_lam,
+                                    star_idx, packed, dtype, x_grad, colsum_partial, rows_per_block, stream);
 }

@@ -3,13 +3,21 @@
 Mirror of training/caiman_asr_train/export/checkpointer.py:20-231: `<name>_step{N}_checkpoint.pt` /
 `_best_` / `_last_` files holding `{epoch, step, best_wer, state_dict, ema_state_dict, optimizer, tokenizer_kw,
 logmel_norm_weight}` (keys pinned by training/tests/export/test_checkpointer.py:76-132).  `state_dict` uses the
-reference's parameter names (RNNT.state_dict drops the aliased joint_fc.* keys), so a checkpoint written by
-either implementation loads in the other.  The inference hand-off file is written by `export/hardware_ckpt.py`.
+reference's parameter names (RNNT.state_dict drops the aliased joint_fc.* keys), so MODEL weights (and the EMA
+weights) written by either implementation load in the other.  The `optimizer` entry does not: this build's FusedLAMB
+keeps its moments in flat arenas (`flat_m`, `flat_v`, `flat_ema`, `layout`), apex's in per-parameter `exp_avg` /
+`exp_avg_sq`; loading a reference checkpoint restores weights, the EMA (copied into the optimiser's EMA arena by
+parameter name) and converts the per-parameter moments into the arenas (`convert_foreign_optimizer_state`; a state
+whose shapes do not match raises a clear error).  `best` / `last`
+checkpoints also get their `.hw.pt` inference hand-off file (`export/hardware_ckpt.py`), as the reference's do
+(checkpointer.py:107-143).
 """
 import glob
+import math
 import os
 import re
 from collections import OrderedDict
+from pathlib import Path
 from typing import Optional
 
 import torch
@@ -61,8 +69,31 @@ class Checkpointer:
             "tokenizer_kw": tokenizer_kw, "logmel_norm_weight": logmel_norm_weight,
         }
         torch.save(state, fpath, pickle_protocol=5)
-        if not is_best and not is_last:
+        if is_best or is_last:
+            self.save_hardware_checkpoint(fpath, logmel_norm_weight, config_path, state["state_dict"])
+        else:
             self.tracked[step] = fpath
+
+    def save_hardware_checkpoint(self, fpath, logmel_norm_weight: float, config_path: Optional[str], model_state_dict) -> Optional[str]:
+        """`<fpath>.hw.pt` next to a best / last checkpoint when the model has one of the supported inference schemas,
+        the log-mel normalisation has finished its ramp to dataset statistics and the training config is known
+        (reference checkpointer.py:107-143).  Returns the path written, or None with the reason printed."""
+        from caiman_asr_amd.export.hardware_ckpt import create_hardware_ckpt, save_hardware_ckpt
+        from caiman_asr_amd.export.model_schema import get_schema, return_schemas
+
+        if config_path is None:
+            print("Not saving hardware checkpoint: no training config path given")
+            return None
+        if get_schema(model_state_dict) not in return_schemas():
+            print("Not saving hardware checkpoint as model is not supported on FPGA")
+            return None
+        if not math.isclose(logmel_norm_weight, 1.0):
+            print(f"Not saving hardware checkpoint as {logmel_norm_weight=} is not yet 1.0")
+            return None
+        out = str(Path(fpath).with_suffix(".hw.pt"))
+        save_hardware_ckpt(create_hardware_ckpt(fpath, config_path), out)
+        print(f"Saved hardware checkpoint to {out}")
+        return out
 
     def last_checkpoint(self):
         tracked = list(self.tracked.values())
@@ -90,8 +121,19 @@ class Checkpointer:
         if ema_model is not None:
             key = "ema_state_dict" if checkpoint.get("ema_state_dict") is not None else "state_dict"
             self._load(_unwrap(ema_model), checkpoint[key])
-        if optimizer is not None and checkpoint.get("optimizer") is not None:
-            optimizer.load_state_dict(checkpoint["optimizer"])
+        opt_sd = checkpoint.get("optimizer")
+        restored_ema = False
+        if optimizer is not None and opt_sd is not None:
+            if isinstance(opt_sd, dict) and "layout" in opt_sd and "flat_m" in opt_sd:
+                optimizer.load_state_dict(opt_sd)
+                restored_ema = opt_sd.get("flat_ema") is not None
+            else:
+                convert_foreign_optimizer_state(optimizer, opt_sd, fpath)
+        if optimizer is not None and getattr(optimizer, "flat_ema", None) is not None and not restored_ema:
+            # the EMA lives in the optimiser's arena: without this it would stay a clone of the weights taken when the
+            # optimiser was built
+            src = checkpoint.get("ema_state_dict") or checkpoint["state_dict"]
+            load_ema_into_optimizer(_unwrap(model), optimizer, src)
         if meta is not None:
             meta["start_epoch"] = checkpoint.get("epoch")
             meta["best_wer"] = checkpoint.get("best_wer", meta["best_wer"])
@@ -111,3 +153,51 @@ def ema_state_dict(model, optimizer):
         p = named.get(k)
         out[k] = by_id[id(p)].detach().clone() if p is not None and id(p) in by_id else v
     return out
+
+
+@torch.no_grad()
+def load_ema_into_optimizer(model, optimizer, ema_sd) -> int:
+    """Copy a name-keyed EMA state_dict into the optimiser's flat EMA arena; returns the number of tensors copied."""
+    views = {id(p): v for p, v in optimizer.ema_tensors().items()}
+    n = 0
+    for name, p in _unwrap(model).named_parameters():
+        key = name if name in ema_sd else name.replace("joint_fc.", "joint_net.2.")
+        v = views.get(id(p))
+        if v is not None and key in ema_sd:
+            v.copy_(torch.as_tensor(ema_sd[key]).to(v.device, v.dtype))
+            n += 1
+    return n
+
+
+@torch.no_grad()
+def convert_foreign_optimizer_state(optimizer, opt_sd, origin="checkpoint") -> None:
+    """A torch-style optimiser state_dict ({"state": {i: {"exp_avg", "exp_avg_sq", ["step"]}}, "param_groups": [{"params":
+    [i, ...], ["step"]}]} -- what apex FusedLAMB, the reference's optimiser, writes) -> this build's moment arenas.
+    Parameter order inside the groups is `model.param_groups(lr)` order in both implementations."""
+    try:
+        state, groups = opt_sd["state"], opt_sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+    except (KeyError, TypeError):
+        raise RuntimeError(f"{origin}: unrecognised optimizer state (keys {sorted(opt_sd) if isinstance(opt_sd, dict) else type(opt_sd)}); "
+                           "expected this build's FusedLAMB arenas or a torch-style {'state', 'param_groups'} dict") from None
+    params = optimizer._params
+    if len(ids) != len(params):
+        raise RuntimeError(f"{origin}: optimizer state holds {len(ids)} parameters, the model has {len(params)} trainable ones")
+    step = 0
+    for i, p, off in zip(ids, params, optimizer._offsets):
+        st = state.get(i, state.get(str(i)))
+        if st is None:
+            continue
+        m, v = st["exp_avg"], st["exp_avg_sq"]
+        if tuple(m.shape) != tuple(p.shape):
+            raise RuntimeError(f"{origin}: optimizer state entry {i} has shape {tuple(m.shape)}, parameter has {tuple(p.shape)}")
+        n = p.numel()
+        optimizer.flat_m[off:off + n].copy_(m.reshape(-1).to(optimizer.flat_m.device, torch.float32))
+        optimizer.flat_v[off:off + n].copy_(v.reshape(-1).to(optimizer.flat_v.device, torch.float32))
+        step = max(step, int(st.get("step", 0)))
+    step = max([step] + [int(g.get("step", 0)) for g in groups])
+    optimizer._step.fill_(step)
+    for g, saved in zip(optimizer.param_groups, groups):
+        for k in ("lr", "weight_decay", "betas", "eps"):
+            if k in saved:
+                g[k] = saved[k]

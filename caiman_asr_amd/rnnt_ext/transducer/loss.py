@@ -17,6 +17,23 @@ import caiman_asr_amd.rnnt_ext.cuda.transducer_loss as transducer_loss_cu
 
 _NO_EOS, _NO_STAR = -1, -2   # sentinels the kernels understand as "feature off" (transducer_loss.cu:396-501)
 
+# The backward kernel can sum the gradient rows it writes (caiman_transducer_loss_backward_colsum): that is the bias
+# gradient of the projection that produced the logits, which autograd would otherwise obtain by one more pass over the
+# whole gradient tensor (5.3 GB at B = 32).  The sums are left here for the projection's backward to pick up
+# (train_utils/overlap.py::_LinearTransposedBackward); nothing changes for a consumer that does not look.
+FUSE_BIAS_GRADIENT = True
+_latest_colsum = None   # (data_ptr, shape, dtype, column sums) of the most recent x_grad
+
+
+def take_bias_gradient(dy: torch.Tensor):
+    """Column sums of `dy` if `dy` IS the gradient tensor the last loss backward produced (same storage, shape, dtype),
+    else None."""
+    global _latest_colsum
+    ent, _latest_colsum = _latest_colsum, None
+    if ent is not None and ent[0] == dy.data_ptr() and ent[1] == tuple(dy.shape) and ent[2] == dy.dtype:
+        return ent[3]
+    return None
+
 
 @dataclass(frozen=True)
 class _LossCall:
@@ -123,7 +140,13 @@ class TransducerLossFunc(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, loss_grad):
+        global _latest_colsum
         x, denom, alpha, beta, f_len, y_len, label, batch_offset = ctx.saved_tensors
-        x_grad = transducer_loss_cu.backward(x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len, label,
-                                             batch_offset, *ctx.call.kernel_args())
+        if FUSE_BIAS_GRADIENT and transducer_loss_cu.colsum_supported(x):
+            x_grad, colsum = transducer_loss_cu.backward_colsum(x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len,
+                                                                label, batch_offset, *ctx.call.kernel_args())
+            _latest_colsum = (x_grad.data_ptr(), tuple(x_grad.shape), x_grad.dtype, colsum)
+        else:
+            x_grad = transducer_loss_cu.backward(x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len, label,
+                                                 batch_offset, *ctx.call.kernel_args())
         return (x_grad,) + (None,) * 13

@@ -19,7 +19,10 @@ Step protocol (one optimiser step may hold several backward passes: gradient acc
     optimizer.step()
 
 A gradient that is accumulated into a bucket whose collective is already in flight would be lost on the other
-ranks (and race with the collective on this one): the hook raises instead of letting that pass silently.
+ranks (and race with the collective on this one): a hook that fires for such a parameter in a LATER backward pass
+raises instead of letting that go silently.  (Within one pass a parameter may report twice -- the LSTM pipelines add
+their weight gradients into `.grad` themselves and notify, and autograd's post-accumulate hook then fires for the same
+parameter although it received no gradient from autograd -- which is harmless and ignored.)
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages beat many small ones,
 so the default bucket is 64 MB (base model: 339 MB of fp32 gradients -> 6 collectives).
@@ -56,7 +59,9 @@ class FlatGradReducer:
                 cur_end, cur_n = cur_start, 0
         if cur_n:
             self.buckets.append((0, cur_end, cur_n))
-        self._ready = [set() for _ in self.buckets]     # ids of the parameters whose gradient is final, per bucket
+        self._ready = [dict() for _ in self.buckets]    # per bucket: id of a parameter whose gradient is final -> pass
+        self._pass = 0              # backward passes seen (advanced by an autograd end-of-pass callback)
+        self._pass_cb_queued = False
         self._handles = []
         self._launched = [False] * len(self.buckets)
         self._syncing = True
@@ -106,7 +111,15 @@ class FlatGradReducer:
         for p in params:
             self._mark(p)
 
+    def _end_of_pass(self):
+        self._pass += 1
+        self._pass_cb_queued = False
+
     def _on_grad(self, p):
+        """post-accumulate-grad hook / notification from a layer pipeline: always inside a backward pass."""
+        if self.world > 1 and not self._pass_cb_queued:
+            self._pass_cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
         if self._syncing:
             self._mark(p)
 
@@ -114,12 +127,15 @@ class FlatGradReducer:
         b = self.param_bucket.get(id(p))
         if b is None or self.world == 1:
             return
-        if self._launched[b]:
-            raise RuntimeError(
-                "FlatGradReducer: a gradient was accumulated into a bucket whose all-reduce is already in flight; "
-                "wrap every backward pass of an optimiser step except the last in reducer.no_sync() "
-                "(gradient accumulation, batch splitting)")
-        self._ready[b].add(id(p))
+        seen = self._ready[b].get(id(p))
+        if seen is not None:
+            if self._launched[b] and seen != self._pass:
+                raise RuntimeError(
+                    "FlatGradReducer: a gradient was accumulated into a bucket whose all-reduce is already in flight; "
+                    "wrap every backward pass of an optimiser step except the last in reducer.no_sync() "
+                    "(gradient accumulation, batch splitting)")
+            return
+        self._ready[b][id(p)] = self._pass
         if len(self._ready[b]) == self.buckets[b][2] and b != self._guard_bucket:
             self._launch(b)
 

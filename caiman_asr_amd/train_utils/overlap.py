@@ -81,7 +81,10 @@ class _LinearTransposedBackward(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.mm(dy2.t(), x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0).to(weight.dtype)
+            from caiman_asr_amd.rnnt_ext.transducer.loss import take_bias_gradient
+
+            db = take_bias_gradient(dy)     # summed inside the loss backward kernel when dy comes straight from it
+            db = (dy2.sum(0) if db is None else db.view(-1)).to(weight.dtype)
         return dx, dw, db
 
 

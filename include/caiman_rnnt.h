@@ -100,6 +100,25 @@ int caiman_transducer_loss_backward(
     double star_lam, int64_t star_idx, int packed, int dtype, void* x_grad,
     caiman_stream_t stream);
 
+/* The same backward pass, also summing the gradient it writes column by column: the bias gradient of the projection
+ * that produced x.  The reference gets it from autograd as `grad_output.sum(0)` for `joint_fc.bias`
+ * (training/caiman_asr_train/rnnt/model.py:201,436-439: an nn.Linear) -- one more pass over the whole gradient.
+ * colsum_partial : workspace of roundup8(nblk * dict_size) + 8 * total_rows floats, 32-byte aligned, nblk =
+ *   ceil(total_rows / rows_per_block).  On return its first [nblk, dict_size] floats hold one partial row per workgroup,
+ *   in a fixed order (deterministic): the caller adds the rows up.  (The rest held one 32-byte descriptor per row:
+ *   everything that is constant along a row.)  rows_per_block: multiple of 4 (64 is a good value).
+ *   Needs x, x_grad 16-byte aligned with dict_size * sizeof(dtype) a multiple of 16, and dict_size <= 16 * 256 * 16 /
+ *   sizeof(dtype) (the sums live in registers); CAIMAN_ERR_INVALID otherwise: use the plain call and reduce.  Sums are
+ *   over the values as rounded to `dtype`. */
+int caiman_transducer_loss_backward_colsum(
+    const void* x, const void* denom, const void* loss_grad, const void* alpha,
+    const void* beta, const int32_t* f_len, const int32_t* y_len,
+    const int32_t* label, const int64_t* batch_offset, int64_t batch,
+    int64_t max_f_len, int64_t max_g_len, int64_t dict_size, int64_t total_rows,
+    double dp_lam, int64_t blank_idx, double eos_lam, int64_t eos_idx,
+    double star_lam, int64_t star_idx, int packed, int dtype, void* x_grad,
+    float* colsum_partial, int64_t rows_per_block, caiman_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * LSTM recurrent passes — replace rnnt_ext.cuda.lstm.lstm_fused_{fwd,bwd}_{soft,hard}
  *   training/lib/csrc/lstm.cu:214-272 / :353-372 (fwd), :274-346 / :377-405 (bwd)

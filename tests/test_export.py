@@ -138,3 +138,32 @@ def test_checkpoint_averaging(tmp_path):
     assert torch.equal(avg["w"], torch.full((2, 2), 2.0)) and torch.equal(avg["b"], torch.tensor([2.0])) and ema is None
     avg, ema = average_checkpoints(paths[:1])
     assert torch.equal(ema["w"], torch.full((2, 2), 10.0))
+
+
+def test_best_checkpoint_gets_its_hardware_file(tmp_path, monkeypatch, capsys):
+    """Checkpointer.save(is_best / is_last) also writes `<name>.hw.pt` when the schema is supported, the norm ramp is
+    complete and the config is known (reference checkpointer.py:107-143); otherwise it says why not."""
+    from caiman_asr_amd.export import model_schema
+    from caiman_asr_amd.export.checkpointer import Checkpointer
+
+    ema, _, cfg = _write_training_run(tmp_path)
+    full = yaml.safe_load(open(cfg))
+    full["ngram"] = {"ngram_path": str(tmp_path), "scale_factor": 0.05}
+    open(cfg, "w").write(yaml.safe_dump(full))
+    (tmp_path / "ngram.binary").write_bytes(b"kenlm")
+    g, sd, m = _mini()
+    m.load_state_dict(sd)
+    ck = Checkpointer(str(tmp_path), "RNN-T")
+    ck.save(m, ema, None, 10, 100, 3.05, {}, 1.0, config_path=cfg, is_best=True)
+    assert "not supported on FPGA" in capsys.readouterr().out and not (tmp_path / "RNN-T_best_checkpoint.hw.pt").exists()
+    mini_schema = model_schema.get_schema(m.state_dict())
+    monkeypatch.setattr(model_schema, "return_schemas", lambda: [mini_schema])
+    ck.save(m, ema, None, 10, 100, 3.05, {}, 0.7, config_path=cfg, is_best=True)
+    assert "is not yet 1.0" in capsys.readouterr().out
+    ck.save(m, ema, None, 10, 100, 3.05, {}, 1.0, is_last=True)
+    assert "no training config" in capsys.readouterr().out
+    ck.save(m, ema, None, 10, 100, 3.05, {}, 1.0, config_path=cfg, is_best=True)
+    hw = torch.load(tmp_path / "RNN-T_best_checkpoint.hw.pt", weights_only=False)
+    assert hw["version"] == HARDWARE_CKPT_VERSION and hw["ngram"]["binary"] == b"kenlm"
+    for k, v in hw["state_dict"].items():
+        assert torch.equal(v, ema[k])

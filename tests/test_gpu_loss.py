@@ -181,3 +181,65 @@ def test_nan_denominator_propagates_and_errors():
         tl.forward(x.transpose(1, 2), x[..., 0].contiguous(), torch.tensor(d["label"], device=DEV),
                    torch.tensor(d["f_len"], device=DEV), torch.tensor(d["y_len"], device=DEV), torch.empty(0),
                    0.0, 3, d["blank"], 0.0, -1, 0.0, -2, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("V,B,T,U", [(29, 3, 9, 5), (8704, 2, 41, 6), (17408, 2, 19, 4)])
+def test_backward_with_fused_column_sums(dtype, packed, V, B, T, U):
+    """caiman_transducer_loss_backward_colsum: the same gradient as the plain backward, bit for bit, plus its column
+    sums (the bias gradient of the projection that produced the logits; the reference takes `grad_output.sum(0)` in a
+    separate pass).  Row counts that are no multiple of the 64 rows a workgroup takes; V = 17 408 needs > 64 KB of LDS."""
+    import caiman_asr_amd.rnnt_ext.cuda.logsumexp as lse
+    import caiman_asr_amd.rnnt_ext.cuda.transducer_loss as tl
+    from tests.helpers import mock_lattice
+
+    d = mock_lattice(B, T, vocab=V, max_decode_length=U + 1, seed=V + B, packed=packed)
+    x = torch.tensor(d["x"], device=DEV).to(dtype).contiguous()
+    label = torch.tensor(d["label"], device=DEV)
+    f_len, y_len = torch.tensor(d["f_len"], device=DEV), torch.tensor(d["y_len"], device=DEV)
+    bo = torch.tensor(d["batch_offset"], device=DEV) if packed else torch.empty(0, device=DEV, dtype=torch.int64)
+    denom = lse.logsumexp(x.view(-1, V), 128, True).view(x.shape[:-1])
+    args = (0.01, d["max_f_len"] if packed else T, d["blank"], 0.0, -1, 0.0, -2, packed)
+    alpha, beta, loss = tl.forward(x, denom, label, f_len, y_len, bo, *args)
+    lg = torch.full((B,), 1.0 / B, device=DEV)
+    ref = tl.backward(x, denom, lg, alpha, beta, f_len, y_len, label, bo, *args)
+    got, colsum = tl.backward_colsum(x, denom, lg, alpha, beta, f_len, y_len, label, bo, *args)
+    assert torch.equal(got, ref)
+    want = ref.view(-1, V).double().sum(0)
+    tol = 1e-6 if dtype == torch.float32 else 1e-5     # fp32 sums of rounded values, a different order than torch's
+    assert torch.allclose(colsum.double(), want, atol=tol * max(1.0, float(want.abs().max())) + 1e-7)
+
+
+def test_projection_backward_picks_up_the_fused_bias_gradient():
+    """The joint projection's backward (train_utils/overlap.py) takes its bias gradient from the loss backward kernel when
+    the gradient tensor it receives is the one that kernel wrote, and falls back to a reduction otherwise."""
+    import caiman_asr_amd.rnnt_ext.transducer.loss as L
+    from caiman_asr_amd.train_utils.overlap import linear_transposed_backward
+    from tests.helpers import mock_lattice
+
+    V, H = 64, 32
+    d = mock_lattice(3, 7, vocab=V, max_decode_length=5, seed=9, packed=True)
+    rows = d["x"].shape[0]
+    torch.manual_seed(0)
+    h = torch.randn(rows, H, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    label = torch.tensor(d["label"], device=DEV)
+    f_len, y_len = torch.tensor(d["f_len"], device=DEV), torch.tensor(d["y_len"], device=DEV)
+    bo = torch.tensor(d["batch_offset"], device=DEV)
+    grads = []
+    for fuse in (True, False):
+        L.FUSE_BIAS_GRADIENT = fuse
+        try:
+            torch.manual_seed(5)
+            w = torch.nn.Parameter(torch.randn(V, H, device=DEV) * 0.2)
+            b = torch.nn.Parameter(torch.zeros(V, device=DEV))
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                logits = linear_transposed_backward(h, w, b)
+                loss = L.TransducerLoss(packed_input=True)(logits, label, f_len, y_len, d["blank"], batch_offset=bo,
+                                                           max_f_len=d["max_f_len"]).mean()
+            loss.backward()
+            assert L._latest_colsum is None          # consumed (or never produced)
+            grads.append(b.grad.clone())
+        finally:
+            L.FUSE_BIAS_GRADIENT = True
+    assert torch.allclose(grads[0], grads[1], atol=2e-3 * float(grads[1].abs().max()) + 1e-6)

@@ -340,3 +340,45 @@ def test_gradcheck_f64_lstm_layer(seq_length, batch_size, input_size, hidden_siz
         return out
 
     assert torch.autograd.gradcheck(stub, [X, W, R, BW, BR])
+
+
+def test_reference_style_checkpoint_restores_ema_arena_and_converts_apex_moments(tmp_path):
+    """ADVICE (round 1): a checkpoint whose optimizer entry is a torch-style per-parameter state (what apex FusedLAMB,
+    the reference's optimiser, writes) must restore the EMA into the optimiser's arena and the moments into flat_m /
+    flat_v instead of raising KeyError; one without optimizer state still restores the EMA."""
+    from caiman_asr_amd.export.checkpointer import Checkpointer
+
+    g, sd, cfg, m = build("tiny")
+    opt = _opt(m)
+    names = [n for n, _ in m.named_parameters()]
+    ema_sd = {k: torch.tensor(v) * 0.5 for k, v in sd.items()}
+    groups, state, i = [], {}, 0
+    for grp in opt.param_groups:
+        ids = []
+        for p in grp["params"]:
+            state[i] = {"exp_avg": torch.full(p.shape, 0.25), "exp_avg_sq": torch.full(p.shape, 0.125), "step": 7}
+            ids.append(i)
+            i += 1
+        groups.append({"params": ids, "lr": grp["lr"], "step": 7})
+    ck = {"epoch": 1, "step": 7, "best_wer": 0.5, "state_dict": {k: torch.tensor(v) for k, v in sd.items()},
+          "ema_state_dict": ema_sd, "optimizer": {"state": state, "param_groups": groups}, "tokenizer_kw": {},
+          "logmel_norm_weight": 1.0}
+    path = tmp_path / "ref_checkpoint.pt"
+    torch.save(ck, path)
+    Checkpointer(str(tmp_path), "RNN-T").load(str(path), m, None, opt, None)
+    for p, e in opt.ema_tensors().items():
+        n = names[[id(q) for q in m.parameters()].index(id(p))].replace("joint_fc.", "joint_net.2.")
+        assert torch.equal(e.cpu(), ema_sd[n]), n
+    used = sum(p.numel() for p in opt._params)
+    assert int(opt._step.item()) == 7
+    assert opt.flat_m.sum().item() == pytest.approx(0.25 * used) and opt.flat_v.sum().item() == pytest.approx(0.125 * used)
+    ck["optimizer"] = None
+    torch.save(ck, path)
+    g, sd, cfg, m2 = build("tiny")
+    opt2 = _opt(m2)
+    Checkpointer(str(tmp_path), "RNN-T").load(str(path), m2, None, opt2, None)
+    assert torch.equal(next(iter(opt2.ema_tensors().values())).cpu(), ema_sd[names[0]])
+    ck["optimizer"] = {"bogus": 1}
+    torch.save(ck, path)
+    with pytest.raises(RuntimeError, match="unrecognised optimizer state"):
+        Checkpointer(str(tmp_path), "RNN-T").load(str(path), m2, None, opt2, None)
