@@ -565,6 +565,9 @@ __device__ __forceinline__ bool res_wait(unsigned* cnt, unsigned target, unsigne
            __hip_atomic_load(fail_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
         __hip_atomic_store(fail_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(fail_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (rare path) leave nothing outstanding: at the join with the normal path the compiler's waitcnt bookkeeping
+        // takes the worst case, and would protect the registers of these two with vmcnt waits in the caller's hot loop
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         return false;
       }
     }
@@ -1121,6 +1124,318 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
 }
 #undef CAIMAN_PROF_MARK
 
+// ===========================================================================
+// Backward resident kernel, 2-D split (H = 512, 1024): the round-1 kernel above gives a workgroup 32 columns of R
+// for ALL of K = 4H, so each of a layer's 32 workgroups pulls the whole dG row of the step before (256 KB at
+// H = 1024) out of L2 every timestep: 4.9 of its 8.0 us (profiles/r01_bench_v13_summary.md).  Same registers, other
+// shape: workgroup bx = (jq = bx / 4, kq = bx % 4) keeps the 128 columns [128 jq, +128) of R for ONE QUARTER of K
+// (the gate rows of units [kq H/4, +H/4): 128 x H elements = 256 KB at H = 1024, 2 x H/32 fragments per wave as
+// before) and therefore gathers a quarter of the row: 64 KB, in H/512 LDS-DMA stages.  The price is a second
+// hand-off per timestep: the four workgroups of a group jq hold the four K-quarter partial sums of the same 128
+// dh columns.  Wave w of every member has the partials of columns [128 jq + 32 w, +32), which is exactly what the
+// member with kq = w finalises (it owns units [32 bx, +32) in the epilogue, as in the round-1 kernel), so a wave sends
+// its 32 x 32 fp32 block (4 KB, write-through) to ONE peer, or keeps it when that peer is its own workgroup; a
+// member receives 3 x 4 KB.  Counters, one 128-byte line each, per slot:
+//   qc[q]  += 1 by each of the NKS/4 workgroups that finalise units of quarter q, once their dG piece of a timestep is
+//            written (write-through, every wave drained): the consumers of quarter q (every workgroup with kq == q)
+//            wait for (NKS/4) * s before gathering at timestep s;
+//   gc[jq] += 1 by each member once its partial blocks are written: members wait for 4 * (round + 1).
+// Both are the hand-off of the visibility table's first row (sc1 stores, drain, barrier, one lane adds; one lane polls,
+// barrier, sc1 loads).  The partial buffers alternate by round parity: a member cannot finish round r + 1 before every
+// peer has produced its round r + 1 block, which it does only after reading its round r blocks, so a block written in
+// round r + 2 never overtakes a reader of round r.  With kq = bx % 4 the four workgroups that share an XCD (blocks are
+// dealt round-robin: bx, bx + 8, .. ) want the SAME quarter: each handed-off line is fetched into an XCD's L2 once and
+// only by the XCDs that need it (2.1x -> ~1x HBM-side traffic).  Placement only changes the speed.
+// Sums are fp32 throughout: four K-quarter partials added in a fixed order (deterministic run to run).
+// ===========================================================================
+constexpr int kRes2CtrPerSlot = 12;                     // qc[4] + gc[8]
+constexpr size_t kRes2PartialFloatsPerSlot = (size_t)2 * 8 * 16 * 1024;   // [parity][jq <= 8][dst 4][src 4][32 x 32]
+constexpr int kResProfBwd2 = 16;                        // fail_host words [16, 24): six phase sums, unused, timesteps
+
+template <typename T, bool HARD, int NKS, bool PROF>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host,
+                                                             float* pws) {
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32;
+  constexpr int NST = H / 512;                           // LDS-DMA stages of 512 columns (1 KB per batch row)
+  constexpr int LDW = 512 + 8;
+  constexpr int KPS = 16;                                // k-steps per stage
+  constexpr int PPQ = NKS / 4;                           // workgroups that finalise units of one K quarter
+  static_assert(H % 512 == 0 && NST >= 1 && NST <= 2, "2-D split kernel: H = 512 or 1024");
+  __shared__ __attribute__((aligned(16))) T ring0[32 * LDW], ring1[NST > 1 ? 32 * LDW : 8];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ownp = reinterpret_cast<float*>(smem);          // [32 batch][32 units + 4]: this workgroup's own partial block
+  int* flag = reinterpret_cast<int*>(ownp + 32 * 36);
+  auto ring = [&](int k) -> T* { return k == 0 ? ring0 : ring1; };
+
+  const int slot = blockIdx.y, bx = blockIdx.x;
+  const int nsteps = w.nsteps[slot];
+  if (nsteps <= 0) return;
+  const int kq = bx & 3, jq = bx >> 2;
+  unsigned* qc_wait = sync + (slot * kRes2CtrPerSlot + kq) * kResCounterStride;
+  unsigned* qc_mine = sync + (slot * kRes2CtrPerSlot + (4 * bx) / NKS) * kResCounterStride;
+  unsigned* gc = sync + (slot * kRes2CtrPerSlot + 4 + jq) * kResCounterStride;
+  unsigned* fail_dev = sync + kMaxSlots * kRes2CtrPerSlot * kResCounterStride;
+  float* pslot = pws + (size_t)slot * kRes2PartialFloatsPerSlot;
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kg = lane >> 4;
+
+  // resident fragments: row tiles (16 units) 8 jq + 2 wave + {0, 1}, k-steps kq NKS + [0, NKS)
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rttile[slot];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)jq * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int i = 0; i < NKS; ++i)
+        wreg[rt][i] = *reinterpret_cast<const frag*>(Rt + ((blk * (4 * NKS) + kq * NKS + i) * 16 + r) * 32 + 8 * kg);
+    }
+  }
+  // epilogue role (as in lstm_bwd_resident with j = bx): batch row eb, units u .. u+3
+  const int eb = tid >> 3, ul4 = (tid & 7) * 4, u = bx * 32 + ul4;
+  const bool ep = eb < B;
+  const int64_t eoff = (int64_t)eb * H + u;
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[q][e] = 0.f;
+  if (ep) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoff);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dcs[q] = v[q];
+  }
+  if (tid == 0) *flag = 0;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+  const int64_t d_st = w.d_st[slot], d_sb = w.d_sb[slot];
+  const int has_in0 = w.has_in0[slot];
+
+  const bool prof = PROF && tid == 0 && slot == 0 && bx == 0;
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
+  if (prof) pt = wall_clock64();
+#define CAIMAN_PROF2(i)                      \
+  if (prof) {                                \
+    const long long now_ = wall_clock64();   \
+    tp[i] += now_ - pt;                      \
+    pt = now_;                               \
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const T* g = w.g[slot] - go * s;
+    const T* c_prev = w.c[slot] - so * s;
+    const T* delta = w.delta[slot] - d_st * s;
+    T* dG = w.dG[slot] - go * s;
+    const bool has_in = s > 0 || has_in0;
+    frag gv0, gv1;
+    g4 cpv, ccv, dlv;
+    if (ep) {   // none of these depends on the recurrence: they travel while the workgroup waits
+      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4);
+      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4 + 8);
+      cpv = *reinterpret_cast<const g4*>(c_prev + eoff);
+      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoff);
+      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)eb * d_sb + u);
+    }
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};   // (dG[t+1] R) for this thread's 4 units, all of K
+    if (has_in) {
+      if (s > 0 && tid == 0) {
+        if (!res_wait(qc_wait, (unsigned)PPQ * (unsigned)s, fail_dev, fail_host)) *flag = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (*flag) break;
+      CAIMAN_PROF2(0)
+      // ---- gather this workgroup's K quarter of dG[t+1] (32 rows x H columns) by LDS-DMA and multiply -------------
+      {
+        const T* src = dG + go + (int64_t)kq * H;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+          T* bq = ring(q);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {   // always 8 instructions per wave and stage (the vmcnt arithmetic counts them)
+            const int b = wave + 4 * i, bs = b < B ? b : B - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (int64_t)bs * 4 * H + q * 512 + lane * 8),
+                (__attribute__((address_space(3))) void*)(bq + b * LDW), 16, 0, 16);
+          }
+        }
+      }
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NST; ++q) {
+        // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
+        // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
+        if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const T* bq = ring(q);
+        constexpr int KB = 4, NB_ = KPS / KB;
+        frag bb[2][KB][2];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          bb[0][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + i * 32 + kg * 8);
+          bb[0][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + i * 32 + kg * 8);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB_; ++nb) {
+          if (nb + 1 < NB_) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+              const int ks = (nb + 1) * KB + i;
+              bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + ks * 32 + kg * 8);
+              bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + ks * 32 + kg * 8);
+            }
+          }
+          // the MFMAs take their operands from this asm: they cannot be hoisted above the reads just issued
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                       :: "memory");
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = q * KPS + nb * KB + i;
+            acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+            acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+            acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+            acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+          }
+        }
+      }
+      CAIMAN_PROF2(1)
+      // ---- hand the partial block of columns [128 jq + 32 wave, +32) to the member that finalises them ----------------
+      // C layout: column lane & 15 = batch row of the column tile, row kg * 4 + reg = unit of the row tile
+      const int round = s - (has_in0 ? 0 : 1);
+      float* pround = pslot + ((size_t)(round & 1) * 8 + jq) * (16 * 1024);
+      if (wave == kq) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            *reinterpret_cast<f32x4*>(ownp + (ct * 16 + r) * 36 + rt * 16 + kg * 4) = acc[rt][ct];
+      } else {
+        const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(wave * 4 + kq) * 1024);   // [dst = wave][src = kq]
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            res_store16(acc[rt][ct], rp, ((ct * 16 + r) * 32 + rt * 16 + kg * 4) * (int)sizeof(float));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CAIMAN_PROF2(2)
+        if (!res_wait(gc, 4u * (unsigned)(round + 1), fail_dev, fail_host)) *flag = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (*flag) break;
+      CAIMAN_PROF2(3)
+      if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
+        f32x4 part[4];
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {
+          if (src == kq) {
+            part[src] = *reinterpret_cast<const f32x4*>(ownp + eb * 36 + ul4);
+          } else {
+            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (eb * 32 + ul4) * (int)sizeof(float), 0, 16);
+            __builtin_memcpy(&part[src], &raw, 16);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+      }
+    }
+    if (ep) {
+      g4 vI, vF, vG, vO;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float dy = static_cast<float>(dlv[q]);
+        if (pd > 0.f) {
+          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
+          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
+        }
+        dy += psum[q];
+        const frag& gv = q < 2 ? gv0 : gv1;
+        const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
+        const float gg = static_cast<float>(gv[(q & 1) * 4 + 2]), go_ = static_cast<float>(gv[(q & 1) * 4 + 3]);
+        const float cp = static_cast<float>(cpv[q]), cc = static_cast<float>(ccv[q]);
+        const float ct = FastAct<HARD>::tanhv(cc);
+        const float dc = dy * go_ * FastAct<HARD>::tanh_prime(ct) + dcs[q];
+        vI[q] = static_cast<T>(dc * gg * FastAct<HARD>::sigm_prime(gi));
+        vF[q] = static_cast<T>(dc * cp * FastAct<HARD>::sigm_prime(gf));
+        vG[q] = static_cast<T>(dc * gi * FastAct<HARD>::tanh_prime(gg));
+        vO[q] = static_cast<T>(dy * ct * FastAct<HARD>::sigm_prime(go_));
+        dcs[q] = dc * gf;
+        bsum[q][0] += static_cast<float>(vI[q]); bsum[q][1] += static_cast<float>(vF[q]);
+        bsum[q][2] += static_cast<float>(vG[q]); bsum[q][3] += static_cast<float>(vO[q]);
+      }
+      frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
+      o0[0] = vI[0]; o0[1] = vF[0]; o0[2] = vG[0]; o0[3] = vO[0]; o0[4] = vI[1]; o0[5] = vF[1]; o0[6] = vG[1]; o0[7] = vO[1];
+      o1[0] = vI[2]; o1[1] = vF[2]; o1[2] = vG[2]; o1[3] = vO[2]; o1[4] = vI[3]; o1[5] = vF[3]; o1[6] = vG[3]; o1[7] = vO[3];
+      const __amdgpu_buffer_rsrc_t ro = res_rsrc(dG);
+      res_store16(o0, ro, (int)(eoff * 4) * (int)sizeof(T));
+      res_store16(o1, ro, (int)(eoff * 4 + 8) * (int)sizeof(T));
+      if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
+        const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+        T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4, 4 * NKS)) = o0;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4 + 8, 4 * NKS)) = o1;
+        f32x4 dv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv[q] = dcs[q];
+        *reinterpret_cast<f32x4*>(w.dC[slot] + eoff) = dv;
+      }
+    }
+    CAIMAN_PROF2(4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(qc_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CAIMAN_PROF2(5)
+  }
+  if (w.dbias[slot] && !*flag) {   // as in lstm_bwd_resident: rows wave * 8 + lane / 8 hold the same units
+    float* red = ownp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bsum[q][e];
+        v += __shfl_xor(v, 8, kWave);
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        bsum[q][e] = v;
+      }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave * 8 + lane) * 16 + q * 4 + e] = bsum[q][e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int cg = tid >> 4, el = tid & 15;
+      const float v = red[(0 * 8 + cg) * 16 + el] + red[(1 * 8 + cg) * 16 + el] + red[(2 * 8 + cg) * 16 + el] +
+                      red[(3 * 8 + cg) * 16 + el];
+      w.dbias[slot][(int64_t)(bx * 32) * 4 + tid] += v;
+    }
+  }
+  if (prof) {
+    for (int i = 0; i < 6; ++i)
+      __hip_atomic_fetch_add(fail_host + kResProfBwd2 + i, (unsigned)tp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfBwd2 + 7, (unsigned)nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+#undef CAIMAN_PROF2
+
+
+
 template <typename T>
 constexpr bool kHasMfma = std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value;
 
@@ -1213,10 +1528,12 @@ int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t 
 
 // ---- resident launch state: per-device pool of zeroed counter blocks + a host-visible failure word ----
 constexpr int kResPool = 32;
-constexpr size_t kResSyncBytes = (size_t)(kMaxSlots + 1) * kResCounterStride * sizeof(unsigned);
+// a launch's counter block: the 2-D split backward kernel needs 12 counters per slot, the others one; + the abort word
+constexpr size_t kResSyncBytes = (size_t)(kMaxSlots * kRes2CtrPerSlot + 1) * kResCounterStride * sizeof(unsigned);
 struct ResState {
   unsigned* sync[kResPool] = {};
   unsigned* fail_host = nullptr;
+  float* partials = nullptr;   // 2-D split backward kernel: K-quarter partial sums in flight between workgroups
   int next = 0;
   int cus = 0;
   int dev = 0;
@@ -1230,6 +1547,7 @@ struct ResState {
 std::mutex g_res_mu;
 ResState g_res[16];
 std::atomic<int> g_res_mode{1};
+std::atomic<int> g_res_bwd_split{1};   // 2-D split backward kernel where the shape allows it (H = 512, 1024)
 std::atomic<long long> g_res_launches{0};
 
 // counter block for one launch; orders the launch behind a resident launch still running on another stream
@@ -1258,8 +1576,10 @@ ResState* res_state() {
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
     st.cus = prop.multiProcessorCount;
     st.dev = dev;
-    if (hipHostMalloc(reinterpret_cast<void**>(&st.fail_host), 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-    for (int i = 0; i < 16; ++i) st.fail_host[i] = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&st.fail_host), 128, hipHostMallocMapped) != hipSuccess) return nullptr;
+    for (int i = 0; i < 32; ++i) st.fail_host[i] = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&st.partials), kMaxSlots * kRes2PartialFloatsPerSlot * sizeof(float)) != hipSuccess)
+      return nullptr;
     for (int i = 0; i < kResPool; ++i)
       if (hipMalloc(reinterpret_cast<void**>(&st.sync[i]), kResSyncBytes) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -1373,6 +1693,43 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
 #undef CAIMAN_RES
   res_end(st, s);
   *err = check_launch("lstm resident backward");
+  return true;
+}
+
+// 2-D split variant (lstm_bwd_resident2): same admission rules, H = 512 or 1024 only
+template <typename T, bool HARD>
+bool try_bwd_resident2(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!g_res_mode.load(std::memory_order_relaxed) || !g_res_bwd_split.load(std::memory_order_relaxed) || B > 32 ||
+      n_launches < 2)
+    return false;
+  if (H != 512 && H != 1024) return false;
+  for (int i = 0; i < n_slots; ++i) {
+    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;
+    if ((reinterpret_cast<uintptr_t>(w.delta[i]) & 7u) || (w.d_sb[i] & 3) || (w.d_st[i] & 3) ||
+        (reinterpret_cast<uintptr_t>(w.dC[i]) & 15u))
+      return false;
+  }
+  const int nks = (int)(H / 32);
+  ResState* st = res_state();
+  if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
+  unsigned* sync = res_begin(st, s);
+  if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
+  const bool prof = g_res_mode.load(std::memory_order_relaxed) == 2;
+#define CAIMAN_RES2(NKV)                                                                                             \
+  do {                                                                                                               \
+    if (prof) hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, true>), grid, dim3(256), lds, s, w, (int)B, sync,  \
+                                 st->fail_host, st->partials);                                                      \
+    else hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, false>), grid, dim3(256), lds, s, w, (int)B, sync,     \
+                            st->fail_host, st->partials);                                                           \
+  } while (0)
+  if (nks == 16) CAIMAN_RES2(16); else CAIMAN_RES2(32);
+#undef CAIMAN_RES2
+  res_end(st, s);
+  *err = check_launch("lstm resident backward (2-D split)");
   return true;
 }
 
@@ -1514,6 +1871,29 @@ extern "C" int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uin
 // previous mode.
 extern "C" int caiman_lstm_resident_mode(int mode) {
   return caiman::g_res_mode.exchange(mode == 2 ? 2 : (mode ? 1 : 0));
+}
+
+// 1 (default): backward wave calls with H = 512 / 1024 use the 2-D split resident kernel (a workgroup gathers a
+// quarter of the dG row, the four K-quarter partials meet in a second hand-off); 0: the round-1 kernel (whole row per
+// workgroup).  Returns the previous setting.  For A/B measurements and tests.
+extern "C" int caiman_lstm_resident_bwd_split(int on) { return caiman::g_res_bwd_split.exchange(on ? 1 : 0); }
+
+// Mode 2 phase timers of the 2-D split backward kernel (workgroup 0 of slot 0), 10 ns ticks summed over timesteps:
+// out8[0..5] = {wait for the quarter's producers, gather + MFMA, partial blocks out + drain, wait for the group,
+// partial blocks in + epilogue, drain + barrier}, out8[6] unused, out8[7] = timesteps; out8[8..14] split "gather + MFMA" into
+// {DMA issue, stage 0 wait, stage 0 MFMA, stage 1 wait, stage 1 MFMA, later stages' waits, later stages' MFMAs}.
+// `out8` has room for 16 values.  Synchronises; clears the counters.
+extern "C" int caiman_lstm_resident_profile_bwd2(uint32_t* out8) {
+  using namespace caiman;
+  int dev = 0;
+  if (!out8 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return CAIMAN_ERR_INVALID;
+  if (hipDeviceSynchronize() != hipSuccess) return check_launch("lstm resident profile");
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  for (int i = 0; i < 16; ++i) out8[i] = 0;
+  if (!g_res[dev].ok) return CAIMAN_OK;
+  volatile unsigned* f = g_res[dev].fail_host;
+  for (int i = 0; i < 16; ++i) { out8[i] = f[kResProfBwd2 + i]; f[kResProfBwd2 + i] = 0; }
+  return CAIMAN_OK;
 }
 
 // Overwrites the failure count (0: re-admit the resident kernels after an incident has been dealt with; tests use a
@@ -1663,6 +2043,9 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
     w.seed = seed;
     if (gate_layout) {
       int err = CAIMAN_OK;
+      if (hard ? try_bwd_resident2<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_bwd_resident2<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
       if (hard ? try_bwd_resident<T, true>(w, n_slots, n_launches, B, H, s, &err)
                : try_bwd_resident<T, false>(w, n_slots, n_launches, B, H, s, &err))
         return err;

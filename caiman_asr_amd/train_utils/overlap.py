@@ -57,6 +57,29 @@ def fence_collectives():
         cur.wait_stream(s)
 
 
+WGRAD_SPLIT = 16   # row chunks of the weight-gradient GEMM when the reduction dimension is long
+
+
+def _weight_gradient(dy2, x2):
+    """dW = dyᵀ · x for [rows, N] x [rows, K] with a very long `rows` (the joint projection: 300 000 lattice cells):
+    the library's transposed-A kernel tiles only the [N, K] output (8704 x 768 = 102 macro-tiles for 256 CUs) and
+    runs at 0.85 PF/s; cut into 16 row chunks as ONE batched GEMM with fp32 outputs and summed, the same product
+    takes 3.98 instead of 4.76 ms (tools/dbg/dw_split2.py) and the partial sums are fp32 instead of one bf16 rounding
+    of the full sum.  Deterministic: the chunks are added in a fixed order."""
+    rows = dy2.shape[0]
+    S = WGRAD_SPLIT
+    if not dy2.is_cuda or dy2.dtype not in (torch.float16, torch.bfloat16) or rows < 4096 * S:
+        return torch.mm(dy2.t(), x2)
+    per = rows // S
+    main = per * S
+    a = dy2[:main].view(S, per, dy2.shape[1])
+    b = x2[:main].view(S, per, x2.shape[1])
+    dw = torch.bmm(a.transpose(1, 2), b, out_dtype=torch.float32).sum(0)
+    if main < rows:
+        dw += torch.mm(dy2[main:].t(), x2[main:], out_dtype=torch.float32)
+    return dw
+
+
 class _LinearTransposedBackward(torch.autograd.Function):
     """F.linear whose input gradient is computed against a [K, N] copy of the weight.  For the joint projection
     (rows x 768 x 8704, bf16) the library's `dY · Wᵀᵀ` (NT) kernel runs at 1.36 PF/s where the usual `dY · W` (NN)
@@ -79,7 +102,7 @@ class _LinearTransposedBackward(torch.autograd.Function):
             wt = weight.to(dy2.dtype).t().contiguous()           # [K, N]
             dx = torch.mm(dy2, wt.t()).view(*dy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = torch.mm(dy2.t(), x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
+            dw = _weight_gradient(dy2, x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from caiman_asr_amd.rnnt_ext.transducer.loss import take_bias_gradient
 

@@ -212,6 +212,15 @@ int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base,
  * non-zero value invalidates the results of that launch; from then on the process keeps to the per-timestep launches) and does not synchronise the device;
  * caiman_lstm_resident_launches counts the wave calls served this way. */
 int caiman_lstm_resident_mode(int mode);
+/* Backward wave calls with H = 512 / 1024: 1 (default) = 2-D split resident kernel (a workgroup keeps 128 columns of R
+ * for one quarter of K and gathers a quarter of the dG row; the four K-quarter partial sums meet in a second hand-off
+ * per timestep), 0 = the whole-row kernel.  Returns the previous setting. */
+int caiman_lstm_resident_bwd_split(int on);
+/* Mode 2 phase timers of the 2-D split kernel: out8[0..5] = 10 ns ticks {wait for the quarter's producers, gather +
+ * MFMA, partial blocks out + drain, wait for the group, partial blocks in + epilogue, drain + barrier}, out8[7] =
+ * timesteps, out8[8..14] = "gather + MFMA" split into {DMA issue, stage 0 wait, stage 0 MFMA, stage 1 wait, stage 1 MFMA,
+ * later waits, later MFMAs}.  `out8` must hold 16 values.  Synchronises the device and clears the counters. */
+int caiman_lstm_resident_profile_bwd2(uint32_t* out8);
 int caiman_lstm_resident_failures(void);
 /* Overwrite the failure count (0 re-admits the resident kernels after an incident); returns the previous value. */
 int caiman_lstm_resident_set_failures(int count);

@@ -126,3 +126,35 @@ def test_resident_geometry_guard_keeps_other_shapes_on_the_step_kernels():
     ga, c, y, dG, _ = _resident_fwd_bwd(R, gates, c0, y0, delta, False, expect_resident=would)
     og, oc, oy = native.lstm_fwd(R.double().numpy(), gates.double().numpy(), c0.double().numpy(), y0.double().numpy())
     assert np.abs(y.double().numpy() - oy).max() <= 16 * BF16_HALF_ULP
+
+
+@pytest.mark.parametrize("H", [512, 1024])
+def test_split_and_whole_row_backward_kernels_agree_and_are_deterministic(H):
+    """The 2-D split backward kernel (H = 512, 1024: a workgroup gathers a quarter of the dG row, K-quarter partial sums
+    meet in a second hand-off) against the round-1 kernel (whole row per workgroup): same arithmetic up to the fp32
+    summation order of the recurrent product; two runs of the split kernel must agree bit for bit (a stale hand-off
+    would show up as a difference); B < 32 exercises the clamped batch rows."""
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    T, B = 37, 23
+    g = torch.Generator().manual_seed(H)
+    dt = torch.bfloat16
+    R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dt)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    y0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    delta = torch.randn(T, B, H, generator=g).to(dt)
+    prev = lib.caiman_lstm_resident_bwd_split(1)
+    try:
+        a1 = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+        a2 = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+        lib.caiman_lstm_resident_bwd_split(0)
+        b = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+    finally:
+        lib.caiman_lstm_resident_bwd_split(prev)
+    for x1, x2 in zip(a1, a2):
+        assert torch.equal(x1, x2)
+    for i, (x1, x2) in enumerate(zip(a1, b)):
+        scale = float(x2.abs().max()) + 1e-6
+        assert torch.allclose(x1.float(), x2.float(), atol=(8e-3 if i < 4 else 2e-2) * scale, rtol=0), i

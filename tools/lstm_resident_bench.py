@@ -87,12 +87,22 @@ def timing(T, B, I, H, L, reps):
     lib.caiman_lstm_resident_mode(2)
     buf = (ctypes.c_uint32 * 10)()
     lib.caiman_lstm_resident_profile(buf)
+    lib.caiman_lstm_resident_profile_bwd2((ctypes.c_uint32 * 16)())
     for _ in range(reps):
         m.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y, _, _ = m(xg, (h0, c0))
         y.float().sum().backward()
     lib.caiman_lstm_resident_profile(buf)
+    buf2 = (ctypes.c_uint32 * 16)()
+    lib.caiman_lstm_resident_profile_bwd2(buf2)
+    v2 = list(buf2)
+    if v2[7]:   # the 2-D split backward kernel served the backward launches
+        names2 = ("wait_quarter", "gather_mfma", "partials_out_drain", "wait_group", "partials_in_epilogue", "drain_barrier")
+        out["bwd2_us_per_timestep"] = {k: round(v2[i] * 0.01 / v2[7], 3) for i, k in enumerate(names2)}
+        out["bwd2_timesteps"] = v2[7]
+        names3 = ("dma_issue", "s0_wait", "s0_mfma", "s1_wait", "s1_mfma", "later_waits", "later_mfma")
+        out["bwd2_gather_split_us"] = {k: round(v2[8 + i] * 0.01 / v2[7], 3) for i, k in enumerate(names3)}
     v = list(buf)
     names = ("wait", "operand_to_lds", "mfma_cell", "drain_barrier")
     for base, tag in ((0, "fwd"), (5, "bwd")):
