@@ -819,6 +819,234 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
   }
 }
 
+// Batch tiles (B > 32): the same kernel with an inner loop over tiles of 32 batch rows.  The resident weights serve every
+// tile; each tile is an INDEPENDENT recurrence with its own hand-off counter, so while the peers of tile bt are still
+// on their way the workgroup multiplies tile bt + 1: the wait for the slowest peer (1.2 of the 4.8 us of a B = 32
+// timestep) disappears behind the other tiles' work, and the poll of a tile's counter is issued one tile ahead.  c is
+// re-read from the row the workgroup wrote a timestep earlier (rounded to the storage type there, exactly what the
+// single-tile kernel keeps in its registers).  Per-timestep launches at B = 128 spend 16.4 ms per training step in the
+// forward recurrence; this kernel ~ 4 tiles x 3.6 us x 560 timesteps.
+constexpr int kResMaxTiles = 4;
+constexpr size_t kResSyncBytesBT = (size_t)(kMaxSlots * kResMaxTiles * 12 + 1) * kResCounterStride * sizeof(unsigned);
+template <typename T, bool HARD, int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32, LDH = H + 8;
+  constexpr bool PROF = false;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* hs = reinterpret_cast<T*>(smem);                       // [32][LDH]
+  T* tr = hs + 32 * LDH;                                    // [4 waves][2: h, c][32 rows][8 units]
+  int* flag = reinterpret_cast<int*>(tr + 4 * 2 * 32 * 8);  // abort broadcast
+
+  const int slot = blockIdx.y, j = blockIdx.x;
+  const int nsteps = w.nsteps[slot];
+  if (nsteps <= 0) return;
+  const int nwg = gridDim.x;
+  const int ntiles = (B + 31) / 32;
+  unsigned* fail_dev = sync + kMaxSlots * kResMaxTiles * 12 * kResCounterStride;
+  auto counter = [&](int bt) -> unsigned* { return sync + ((slot * kResMaxTiles + bt) * 12) * kResCounterStride; };
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int u0 = j * 32 + wave * 8;   // first hidden unit of this wave
+
+  // resident A fragments: row m of a 16-row tile = (unit m>>2, gate m&3); tile_R_fwd_kernel stores n = gate*4 + unit
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rtile[slot];
+    const int n = (r & 3) * 4 + (r >> 2);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)j * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) wreg[rt][s] = *reinterpret_cast<const frag*>(Rt + ((blk * NKS + s) * 16 + n) * 32 + 8 * kq);
+    }
+  }
+  // this lane's cells: unit u0 + rt*4 + kq, batch row (32 bt) + ct*16 + r
+  g4 gcur[2][2], gnext[2][2];
+  auto load_gates = [&](int s_, int bt_, g4 (&dst)[2][2]) {
+    const T* g_ = w.g[slot] + go * s_;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = bt_ * 32 + ct * 16 + r, u = u0 + rt * 4 + kq;
+        if (b < B) dst[rt][ct] = *reinterpret_cast<const g4*>(g_ + ((int64_t)b * H + u) * 4);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[rt][ct][q] = static_cast<T>(0.f);
+        }
+      }
+  };
+  load_gates(0, 0, gnext);
+  unsigned pre_next = 0;   // (thread 0) the next tile-step's counter, polled a tile ahead
+  if (tid == 0) *flag = 0;
+  T* trh = tr + wave * (2 * 32 * 8);
+  T* trc = trh + 32 * 8;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+
+  bool aborted = false;
+  for (int s = 0; s < nsteps && !aborted; ++s) {
+   for (int bt = 0; bt < ntiles; ++bt) {
+    T* g = w.g[slot] + go * s;
+    unsigned* cnt = counter(bt);
+    const int row0 = bt * 32;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) gcur[rt][ct] = gnext[rt][ct];
+    // the next tile-step in program order: its pre-activations and its c row do not depend on this one
+    const int bt_n = bt + 1 < ntiles ? bt + 1 : 0, s_n = bt + 1 < ntiles ? s : s + 1;
+    if (s_n < nsteps) load_gates(s_n, bt_n, gnext);
+    float creg[2][2];
+    {
+      const T* cp = w.c[slot] + so * s;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int b = row0 + ct * 16 + r, u = u0 + rt * 4 + kq;
+          creg[rt][ct] = b < B ? static_cast<float>(cp[(int64_t)b * H + u]) : 0.f;
+        }
+    }
+    if (s > 0 && tid == 0) {
+      const unsigned target = (unsigned)nwg * (unsigned)s;
+      if (pre_next < target && !res_wait(cnt, target, fail_dev, fail_host)) *flag = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+    if (*flag) { aborted = true; break; }
+    // h of this step: row s of y, [B][H] row-major -> LDS (rows >= B are zero).  Every load of handed-off bytes is
+    // an sc1 load to registers, which stands in for the agent acquire (visibility table, first row).
+    {
+      const __amdgpu_buffer_rsrc_t rs = res_rsrc(w.y[slot] + so * s);
+      constexpr int PER = (32 * H / 8 + 255) / 256;   // 16-byte pieces per thread
+      frag v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+        if (row0 + b < B) v[i] = res_load16<T>(rs, ((row0 + b) * H + k8 * 8) * (int)sizeof(T));
+        else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[i][q] = static_cast<T>(0.f);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + 256 * i, b = idx / (H / 8), k8 = idx % (H / 8);
+        if (b < 32) *reinterpret_cast<frag*>(hs + b * LDH + k8 * 8) = v[i];
+      }
+    }
+    if (tid == 0 && s_n > 0 && s_n < nsteps)   // poll the next tile-step's counter now: the answer travels under the MFMAs
+      pre_next = __hip_atomic_load(counter(bt_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LDS reads run a batch of KB k-steps ahead of the MFMAs that consume them: left to itself the compiler, short
+    // of registers, put one read and a full wait in front of every pair of MFMAs (2.7 us of exposed LDS latency per
+    // timestep).  The empty asm pins the order: the next batch's reads are issued before this batch's MFMAs.
+    {
+      constexpr int KB = (NKS % 4 == 0) ? 4 : 2, NB_ = NKS / KB;
+      frag bb[2][KB][2];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        bb[0][i][0] = *reinterpret_cast<const frag*>(hs + r * LDH + i * 32 + kq * 8);
+        bb[0][i][1] = *reinterpret_cast<const frag*>(hs + (16 + r) * LDH + i * 32 + kq * 8);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB_; ++nb) {
+        if (nb + 1 < NB_) {
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (nb + 1) * KB + i;
+            bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(hs + r * LDH + ks * 32 + kq * 8);
+            bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(hs + (16 + r) * LDH + ks * 32 + kq * 8);
+          }
+        }
+        // the MFMAs below take their operands from this asm, so they cannot be hoisted back above the reads just issued
+        if constexpr (KB == 4)
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                       :: "memory");
+        else
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1])
+                       :: "memory");
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const int ks = nb * KB + i;
+          acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+          acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+          acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+          acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+        }
+      }
+    }
+    // cell update, lane-local: acc register q = gate q of (unit kq of the row tile, batch row r of the column tile)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = ct * 16 + r, ul = rt * 4 + kq;   // row within the tile
+        const float pi = static_cast<float>(gcur[rt][ct][0]) + acc[rt][ct][0];
+        const float pf = static_cast<float>(gcur[rt][ct][1]) + acc[rt][ct][1];
+        const float pg = static_cast<float>(gcur[rt][ct][2]) + acc[rt][ct][2];
+        const float po = static_cast<float>(gcur[rt][ct][3]) + acc[rt][ct][3];
+        const float ig = FastAct<HARD>::sigm(pi), fg = FastAct<HARD>::sigm(pf);
+        const float gg = FastAct<HARD>::tanhv(pg), og = FastAct<HARD>::sigm(po);
+        const float c = ig * gg + fg * creg[rt][ct];
+        const T cv = static_cast<T>(c);
+        const T yv = static_cast<T>(og * FastAct<HARD>::tanhv(c));
+        creg[rt][ct] = static_cast<float>(cv);
+        trh[b * 8 + ul] = yv;
+        trc[b * 8 + ul] = cv;
+        if (row0 + b < B) {
+          g4 v;
+          v[0] = static_cast<T>(ig); v[1] = static_cast<T>(fg); v[2] = static_cast<T>(gg); v[3] = static_cast<T>(og);
+          *reinterpret_cast<g4*>(g + ((int64_t)(row0 + b) * H + u0 + ul) * 4) = v;
+        }
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      // lane -> (batch row lane>>1, 4 units): one 8-byte piece of the h row (write-through) and of the c row
+      const int bl = lane >> 1, half = lane & 1, b = row0 + bl;
+      if (b < B) {
+        const g4 hv = *reinterpret_cast<const g4*>(trh + bl * 8 + half * 4);
+        const g4 cv = *reinterpret_cast<const g4*>(trc + bl * 8 + half * 4);
+        const int64_t e = (int64_t)b * H + u0 + half * 4;
+        unsigned long long hbits;
+        __builtin_memcpy(&hbits, &hv, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(w.y[slot] + so * (s + 1) + e), hbits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
+        if (w.ymask[slot]) {
+          g4 mv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
+            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
+          }
+          *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
+        }
+        if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
+          const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+          T* h_out = w.hring[slot] + ((w.parity[slot] + nsteps) & 1) * hsz;
+          *reinterpret_cast<g4*>(h_out + tiled_index(b, u0 + half * 4, NKS)) = hv;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+  }
+}
+
 // Backward counterpart: dh[t] = delta[t] + dG[t+1]·R with K = 4H.  A workgroup owns 32 hidden units and keeps the
 // matching 32 columns of R (as rows of Rᵀ, all 4H of K: again 256 KB at H = 1024) in registers: wave (rt, kh) holds
 // the 16-unit row tile rt for half of the k-steps.  The operand every workgroup needs is the whole dG row of the
@@ -1434,6 +1662,283 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
 }
 #undef CAIMAN_PROF2
 
+// Batch tiles (B > 32) of the 2-D split kernel: an inner loop over tiles of 32 batch rows, each an independent
+// recurrence with its own twelve counters and partial-sum buffers (see lstm_fwd_resident_bt).  dC of a tile lives in
+// its fp32 buffer between a tile's timesteps (the thread that wrote it reads it back); the bias-gradient sums run over
+// all tiles in registers.
+template <typename T, bool HARD, int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host,
+                                                                float* pws) {
+  constexpr bool PROF = false;
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32;
+  constexpr int NST = H / 512;                           // LDS-DMA stages of 512 columns (1 KB per batch row)
+  constexpr int LDW = 512 + 8;
+  constexpr int KPS = 16;                                // k-steps per stage
+  constexpr int PPQ = NKS / 4;                           // workgroups that finalise units of one K quarter
+  static_assert(H % 512 == 0 && NST >= 1 && NST <= 2, "2-D split kernel: H = 512 or 1024");
+  __shared__ __attribute__((aligned(16))) T ring0[32 * LDW], ring1[NST > 1 ? 32 * LDW : 8];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ownp = reinterpret_cast<float*>(smem);          // [32 batch][32 units + 4]: this workgroup's own partial block
+  int* flag = reinterpret_cast<int*>(ownp + 32 * 36);
+  auto ring = [&](int k) -> T* { return k == 0 ? ring0 : ring1; };
+
+  const int slot = blockIdx.y, bx = blockIdx.x;
+  const int nsteps = w.nsteps[slot];
+  if (nsteps <= 0) return;
+  const int kq = bx & 3, jq = bx >> 2;
+  const int ntiles = (B + 31) / 32;
+  unsigned* fail_dev = sync + kMaxSlots * kResMaxTiles * 12 * kResCounterStride;
+  auto counters = [&](int bt) -> unsigned* { return sync + ((slot * kResMaxTiles + bt) * 12) * kResCounterStride; };
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kg = lane >> 4;
+
+  // resident fragments: row tiles (16 units) 8 jq + 2 wave + {0, 1}, k-steps kq NKS + [0, NKS)
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rttile[slot];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)jq * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int i = 0; i < NKS; ++i)
+        wreg[rt][i] = *reinterpret_cast<const frag*>(Rt + ((blk * (4 * NKS) + kq * NKS + i) * 16 + r) * 32 + 8 * kg);
+    }
+  }
+  // epilogue role (as in lstm_bwd_resident with j = bx): batch row eb, units u .. u+3
+  const int ebl = tid >> 3, ul4 = (tid & 7) * 4, u = bx * 32 + ul4;   // row within the tile
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[q][e] = 0.f;
+  if (tid == 0) *flag = 0;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+  const int64_t d_st = w.d_st[slot], d_sb = w.d_sb[slot];
+  const int has_in0 = w.has_in0[slot];
+
+  bool aborted = false;
+  unsigned pre_q = 0;   // (thread 0) the next tile-step's quarter counter, polled a tile ahead
+  for (int s = 0; s < nsteps && !aborted; ++s) {
+   for (int bt = 0; bt < ntiles; ++bt) {
+    unsigned* ctr = counters(bt);
+    unsigned* qc_wait = ctr + kq * kResCounterStride;
+    unsigned* qc_mine = ctr + ((4 * bx) / NKS) * kResCounterStride;
+    unsigned* gc = ctr + (4 + jq) * kResCounterStride;
+    float* pslot = pws + (size_t)(slot * kResMaxTiles + bt) * kRes2PartialFloatsPerSlot;
+    const int row0 = bt * 32, eb = row0 + ebl;
+    const bool ep = eb < B;
+    const int64_t eoff = (int64_t)eb * H + u;
+    const int bt_n = bt + 1 < ntiles ? bt + 1 : 0, s_n = bt + 1 < ntiles ? s : s + 1;
+    const T* g = w.g[slot] - go * s;
+    const T* c_prev = w.c[slot] - so * s;
+    const T* delta = w.delta[slot] - d_st * s;
+    T* dG = w.dG[slot] - go * s;
+    const bool has_in = s > 0 || has_in0;
+    frag gv0, gv1;
+    g4 cpv, ccv, dlv;
+    if (ep) {   // none of these depends on the recurrence: they travel while the workgroup waits
+      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4);
+      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4 + 8);
+      cpv = *reinterpret_cast<const g4*>(c_prev + eoff);
+      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoff);
+      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)eb * d_sb + u);
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoff);   // written by this thread a timestep ago
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dcs[q] = dv[q];
+    }
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};   // (dG[t+1] R) for this thread's 4 units, all of K
+    if (has_in) {
+      if (s > 0 && tid == 0) {
+        const unsigned target = (unsigned)PPQ * (unsigned)s;
+        if (pre_q < target && !res_wait(qc_wait, target, fail_dev, fail_host)) *flag = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (*flag) { aborted = true; break; }
+      // ---- gather this workgroup's K quarter of dG[t+1] (32 rows x H columns) by LDS-DMA and multiply -------------
+      {
+        const T* src = dG + go + (int64_t)kq * H;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+          T* bq = ring(q);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {   // always 8 instructions per wave and stage (the vmcnt arithmetic counts them)
+            const int b = wave + 4 * i, bg = row0 + b, bs = bg < B ? bg : B - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (int64_t)bs * 4 * H + q * 512 + lane * 8),
+                (__attribute__((address_space(3))) void*)(bq + b * LDW), 16, 0, 16);
+          }
+        }
+      }
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NST; ++q) {
+        // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
+        // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
+        if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const T* bq = ring(q);
+        constexpr int KB = 4, NB_ = KPS / KB;
+        frag bb[2][KB][2];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          bb[0][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + i * 32 + kg * 8);
+          bb[0][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + i * 32 + kg * 8);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB_; ++nb) {
+          if (nb + 1 < NB_) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+              const int ks = (nb + 1) * KB + i;
+              bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + ks * 32 + kg * 8);
+              bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + ks * 32 + kg * 8);
+            }
+          }
+          // the MFMAs take their operands from this asm: they cannot be hoisted above the reads just issued
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                       :: "memory");
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = q * KPS + nb * KB + i;
+            acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+            acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+            acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+            acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+          }
+        }
+      }
+      if (tid == 0 && s_n > 0 && s_n < nsteps)   // poll the next tile-step's quarter counter under the hand-off below
+        pre_q = __hip_atomic_load(counters(bt_n) + kq * kResCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---- hand the partial block of columns [128 jq + 32 wave, +32) to the member that finalises them ----------------
+      // C layout: column lane & 15 = batch row of the column tile, row kg * 4 + reg = unit of the row tile
+      const int round = s - (has_in0 ? 0 : 1);
+      float* pround = pslot + ((size_t)(round & 1) * 8 + jq) * (16 * 1024);
+      if (wave == kq) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            *reinterpret_cast<f32x4*>(ownp + (ct * 16 + r) * 36 + rt * 16 + kg * 4) = acc[rt][ct];
+      } else {
+        const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(wave * 4 + kq) * 1024);   // [dst = wave][src = kq]
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            res_store16(acc[rt][ct], rp, ((ct * 16 + r) * 32 + rt * 16 + kg * 4) * (int)sizeof(float));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!res_wait(gc, 4u * (unsigned)(round + 1), fail_dev, fail_host)) *flag = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (*flag) { aborted = true; break; }
+      if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
+        f32x4 part[4];
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {
+          if (src == kq) {
+            part[src] = *reinterpret_cast<const f32x4*>(ownp + ebl * 36 + ul4);
+          } else {
+            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (ebl * 32 + ul4) * (int)sizeof(float), 0, 16);
+            __builtin_memcpy(&part[src], &raw, 16);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+      }
+    }
+    if (ep) {
+      g4 vI, vF, vG, vO;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float dy = static_cast<float>(dlv[q]);
+        if (pd > 0.f) {
+          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
+          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
+        }
+        dy += psum[q];
+        const frag& gv = q < 2 ? gv0 : gv1;
+        const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
+        const float gg = static_cast<float>(gv[(q & 1) * 4 + 2]), go_ = static_cast<float>(gv[(q & 1) * 4 + 3]);
+        const float cp = static_cast<float>(cpv[q]), cc = static_cast<float>(ccv[q]);
+        const float ct = FastAct<HARD>::tanhv(cc);
+        const float dc = dy * go_ * FastAct<HARD>::tanh_prime(ct) + dcs[q];
+        vI[q] = static_cast<T>(dc * gg * FastAct<HARD>::sigm_prime(gi));
+        vF[q] = static_cast<T>(dc * cp * FastAct<HARD>::sigm_prime(gf));
+        vG[q] = static_cast<T>(dc * gi * FastAct<HARD>::tanh_prime(gg));
+        vO[q] = static_cast<T>(dy * ct * FastAct<HARD>::sigm_prime(go_));
+        dcs[q] = dc * gf;
+        bsum[q][0] += static_cast<float>(vI[q]); bsum[q][1] += static_cast<float>(vF[q]);
+        bsum[q][2] += static_cast<float>(vG[q]); bsum[q][3] += static_cast<float>(vO[q]);
+      }
+      frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
+      o0[0] = vI[0]; o0[1] = vF[0]; o0[2] = vG[0]; o0[3] = vO[0]; o0[4] = vI[1]; o0[5] = vF[1]; o0[6] = vG[1]; o0[7] = vO[1];
+      o1[0] = vI[2]; o1[1] = vF[2]; o1[2] = vG[2]; o1[3] = vO[2]; o1[4] = vI[3]; o1[5] = vF[3]; o1[6] = vG[3]; o1[7] = vO[3];
+      const __amdgpu_buffer_rsrc_t ro = res_rsrc(dG);
+      res_store16(o0, ro, (int)(eoff * 4) * (int)sizeof(T));
+      res_store16(o1, ro, (int)(eoff * 4 + 8) * (int)sizeof(T));
+      if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
+        const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+        T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4, 4 * NKS)) = o0;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4 + 8, 4 * NKS)) = o1;
+      }
+      f32x4 dv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dv[q] = dcs[q];
+      *reinterpret_cast<f32x4*>(w.dC[slot] + eoff) = dv;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(qc_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+  }
+  if (w.dbias[slot] && !*flag) {   // as in lstm_bwd_resident: rows wave * 8 + lane / 8 hold the same units
+    float* red = ownp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bsum[q][e];
+        v += __shfl_xor(v, 8, kWave);
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        bsum[q][e] = v;
+      }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave * 8 + lane) * 16 + q * 4 + e] = bsum[q][e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int cg = tid >> 4, el = tid & 15;
+      const float v = red[(0 * 8 + cg) * 16 + el] + red[(1 * 8 + cg) * 16 + el] + red[(2 * 8 + cg) * 16 + el] +
+                      red[(3 * 8 + cg) * 16 + el];
+      w.dbias[slot][(int64_t)(bx * 32) * 4 + tid] += v;
+    }
+  }
+}
+
+
 
 
 template <typename T>
@@ -1534,6 +2039,9 @@ struct ResState {
   unsigned* sync[kResPool] = {};
   unsigned* fail_host = nullptr;
   float* partials = nullptr;   // 2-D split backward kernel: K-quarter partial sums in flight between workgroups
+  float* partials_bt = nullptr;         // batch-tile kernels (B > 32): allocated on first use
+  unsigned* sync_bt[kResPool] = {};
+  int next_bt = 0;
   int next = 0;
   int cus = 0;
   int dev = 0;
@@ -1730,6 +2238,87 @@ bool try_bwd_resident2(const BwdSlots<T>& w, int n_slots, int n_launches, int64_
 #undef CAIMAN_RES2
   res_end(st, s);
   *err = check_launch("lstm resident backward (2-D split)");
+  return true;
+}
+
+// ---- batch-tile launches (32 < B <= 128): lstm_fwd_resident_bt / lstm_bwd_resident2_bt ----------------------------
+bool res_bt_ready(ResState* st) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  if (st->partials_bt) return true;
+  for (int i = 0; i < kResPool; ++i)
+    if (hipMalloc(reinterpret_cast<void**>(&st->sync_bt[i]), kResSyncBytesBT) != hipSuccess) return false;
+  return hipMalloc(reinterpret_cast<void**>(&st->partials_bt),
+                   (size_t)kMaxSlots * kResMaxTiles * kRes2PartialFloatsPerSlot * sizeof(float)) == hipSuccess;
+}
+unsigned* res_begin_bt(ResState* st, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  unsigned* sync = st->sync_bt[st->next_bt];
+  st->next_bt = (st->next_bt + 1) % kResPool;
+  if (st->has_last && st->last_stream != s) (void)hipStreamWaitEvent(s, st->done, 0);
+  return sync;
+}
+
+template <typename T, bool HARD>
+bool try_fwd_resident_bt(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!g_res_mode.load(std::memory_order_relaxed) || B <= 32 || B > 32 * kResMaxTiles || n_launches < 2) return false;
+  if (H != 256 && H != 512 && H != 1024) return false;
+  for (int i = 0; i < n_slots; ++i)
+    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;
+  const int nks = (int)(H / 32);
+  ResState* st = res_state();
+  if (!st || (int64_t)n_slots * nks > st->cus || !res_bt_ready(st)) return false;
+  if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
+  unsigned* sync = res_begin_bt(st, s);
+  if (hipMemsetAsync(sync, 0, kResSyncBytesBT, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const size_t lds = res_fwd_lds<T>((int)H);
+#define CAIMAN_RESBT(NKV)                                                                                            \
+  do {                                                                                                               \
+    auto kern = lstm_fwd_resident_bt<T, HARD, NKV>;                                                                  \
+    static bool attr_set[16] = {};                                                                                   \
+    if (!attr_set[st->dev]) {                                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)res_fwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
+        *err = check_launch("lstm resident attribute");                                                              \
+        return true;                                                                                                 \
+      }                                                                                                              \
+      attr_set[st->dev] = true;                                                                                      \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
+  } while (0)
+  if (nks == 8) CAIMAN_RESBT(8); else if (nks == 16) CAIMAN_RESBT(16); else CAIMAN_RESBT(32);
+#undef CAIMAN_RESBT
+  res_end(st, s);
+  *err = check_launch("lstm resident forward (batch tiles)");
+  return true;
+}
+
+template <typename T, bool HARD>
+bool try_bwd_resident2_bt(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!g_res_mode.load(std::memory_order_relaxed) || B <= 32 || B > 32 * kResMaxTiles || n_launches < 2) return false;
+  if (H != 512 && H != 1024) return false;
+  for (int i = 0; i < n_slots; ++i) {
+    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;
+    if ((reinterpret_cast<uintptr_t>(w.delta[i]) & 7u) || (w.d_sb[i] & 3) || (w.d_st[i] & 3) ||
+        (reinterpret_cast<uintptr_t>(w.dC[i]) & 15u))
+      return false;
+  }
+  const int nks = (int)(H / 32);
+  ResState* st = res_state();
+  if (!st || (int64_t)n_slots * nks > st->cus || !res_bt_ready(st)) return false;
+  if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
+  unsigned* sync = res_begin_bt(st, s);
+  if (hipMemsetAsync(sync, 0, kResSyncBytesBT, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
+  if (nks == 16)
+    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt);
+  else
+    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt);
+  res_end(st, s);
+  *err = check_launch("lstm resident backward (2-D split, batch tiles)");
   return true;
 }
 
@@ -1930,7 +2519,8 @@ extern "C" int caiman_lstm_resident_profile(uint32_t* out10) {
 // gradients (`dbias`): the per-timestep path fills them too, but with an extra reduction launch per call.
 extern "C" int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots) {
   using namespace caiman;
-  if (!g_res_mode.load(std::memory_order_relaxed) || B < 1 || B > 32 || H % 32 != 0 || n_slots < 1 || n_slots > kMaxSlots) return 0;
+  if (!g_res_mode.load(std::memory_order_relaxed) || B < 1 || H % 32 != 0 || n_slots < 1 || n_slots > kMaxSlots) return 0;
+  if (B > 32 && (B > 32 * kResMaxTiles || (H != 512 && H != 1024))) return 0;   // batch tiles: the backward kernel's shapes
   const int nks = (int)(H / 32);
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return 0;
   ResState* st = res_state();
@@ -1998,6 +2588,9 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
     w.seed = seed;
     if (gate_layout) {
       int err = CAIMAN_OK;
+      if (hard ? try_fwd_resident_bt<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_fwd_resident_bt<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
       if (hard ? try_fwd_resident<T, true>(w, n_slots, n_launches, B, H, s, &err)
                : try_fwd_resident<T, false>(w, n_slots, n_launches, B, H, s, &err))
         return err;
@@ -2043,6 +2636,9 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
     w.seed = seed;
     if (gate_layout) {
       int err = CAIMAN_OK;
+      if (hard ? try_bwd_resident2_bt<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_bwd_resident2_bt<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
       if (hard ? try_bwd_resident2<T, true>(w, n_slots, n_launches, B, H, s, &err)
                : try_bwd_resident2<T, false>(w, n_slots, n_launches, B, H, s, &err))
         return err;

@@ -204,8 +204,8 @@ int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_slots, int n
 int caiman_lstm_dropout_mask(void* out, int64_t n, uint64_t seed, uint64_t base, float p, int dtype,
                              caiman_stream_t stream);
 /* Weight-resident variant of the wave calls (same slots, same results up to fp32 summation order): with mode 1
- * (the default) a wave call whose shapes allow it (interleaved gates, B <= 32, one hidden size, n_slots * H/32 workgroups not more
- * than the device has CUs) runs ALL its timesteps in one launch, each workgroup keeping its rows of R in registers
+ * (the default) a wave call whose shapes allow it (interleaved gates, one hidden size, n_slots * H/32 workgroups not more
+ * than the device has CUs; B <= 32, or up to 128 in tiles of 32 batch rows for H = 512 / 1024) runs ALL its timesteps in one launch, each workgroup keeping its rows of R in registers
  * and the workgroups of a slot meeting at a device counter once per timestep; other calls keep the per-timestep
  * launches.  Replaces the same time loop (training/lib/csrc/lstm.cu:214-346).  caiman_lstm_resident_mode returns the
  * previous mode; caiman_lstm_resident_failures counts workgroups that timed out waiting (0 in a healthy process; a
@@ -230,8 +230,9 @@ int caiman_lstm_resident_set_failures(int count);
  * no resident launch has been attempted on the device. */
 int caiman_lstm_resident_poison(float* grad_elem, const uint32_t* seen, caiman_stream_t stream);
 int64_t caiman_lstm_resident_launches(void);
-/* 1 when a multi-timestep wave call with n_slots slots of hidden size H and batch B would be one resident launch on
- * the current device (mode on, B <= 32, H/32 in {2,4,8,16,24,32}, n_slots * H/32 <= CUs). */
+/* 1 when a multi-timestep BACKWARD wave call with n_slots slots of hidden size H and batch B would be one resident
+ * launch on the current device (mode on, n_slots * H/32 <= CUs, and B <= 32 with H/32 in {2,4,8,16,24,32}, or
+ * 32 < B <= 128 in tiles of 32 batch rows with H in {512, 1024}; the forward call also takes H = 256 in tiles). */
 int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots);
 /* Diagnostic: mode 2 = mode 1 plus phase timers in one workgroup (slot 0, first slice).  out10[0..4] forward and
  * out[5..9] backward: 10 ns ticks spent {waiting for the peers' hand-off, bringing the operand row into LDS (backward:

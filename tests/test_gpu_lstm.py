@@ -305,7 +305,8 @@ def _run_stack(m, x, h0, c0, w, dtype, mode):
 
 
 @pytest.mark.parametrize("T,B,I,H,L,p", [(40, 3, 16, 64, 2, 0.0), (70, 32, 48, 128, 3, 0.0), (150, 17, 64, 256, 4, 0.0),
-                                         (90, 8, 64, 512, 3, 0.3), (50, 32, 64, 768, 2, 0.2), (70, 32, 64, 1024, 3, 0.0)])
+                                         (90, 8, 64, 512, 3, 0.3), (50, 32, 64, 768, 2, 0.2), (70, 32, 64, 1024, 3, 0.0),
+                                         (70, 64, 64, 512, 3, 0.2), (45, 128, 64, 1024, 2, 0.0), (40, 77, 32, 1024, 2, 0.1)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_resident_chunk_kernels_match_step_kernels(T, B, I, H, L, p, dtype):
     """csrc/lstm.hip, weight-resident chunk kernels: one launch runs every timestep of a pipeline tick, the
@@ -366,9 +367,14 @@ def test_resident_kernels_under_uneven_load_and_fallbacks():
         for a, b in zip(quiet, busy):
             assert torch.equal(a, b)
     assert _lib.lib().caiman_lstm_resident_failures() == 0
+    # B > 32: tiles of 32 batch rows at H = 512 / 1024 (resident), per-timestep launches at other hidden sizes
     xb = torch.randn(T, 40, I, device=DEV)
     _, n = _run_stack(m, xb, torch.zeros(L, 40, H, device=DEV), torch.zeros(L, 40, H, device=DEV),
                       torch.randn(T, 40, H, device=DEV), torch.bfloat16, 1)
+    assert n > 0
+    m2 = CustomLSTM(I, 128, 2, device=DEV)
+    _, n = _run_stack(m2, xb, torch.zeros(2, 40, 128, device=DEV), torch.zeros(2, 40, 128, device=DEV),
+                      torch.randn(T, 40, 128, device=DEV), torch.bfloat16, 1)
     assert n == 0
 
 

@@ -73,7 +73,9 @@ def _resident_fwd_bwd(R, gates_ref, c0, y0, delta, hard, expect_resident=True):
     return (_ref(G.cpu(), H), C.cpu(), Y.cpu(), _ref(dG.cpu(), H), _ref(dbias.cpu(), H))
 
 
-@pytest.mark.parametrize("T,B,H", [(40, 32, 128), (40, 32, 1024), (33, 7, 256), (24, 32, 768)])
+@pytest.mark.parametrize("T,B,H", [(40, 32, 128), (40, 32, 1024), (33, 7, 256), (24, 32, 768),
+                                   # batch tiles of 32 rows (lstm_fwd_resident_bt / lstm_bwd_resident2_bt): ragged, 2 and 4 tiles
+                                   (12, 33, 512), (10, 64, 1024), (6, 128, 1024), (10, 100, 512)])
 @pytest.mark.parametrize("hard", [False, True])
 def test_resident_kernels_match_the_f64_oracle(T, B, H, hard):
     from oracle import native
@@ -109,7 +111,8 @@ def test_resident_kernels_match_the_f64_oracle(T, B, H, hard):
 
 
 def test_resident_geometry_guard_keeps_other_shapes_on_the_step_kernels():
-    """B > 32 (until batch tiles are resident) must be served by the per-timestep kernels, with the same oracle bound."""
+    """Shapes outside the resident kernels' geometry (B > 32 at a hidden size the batch-tile kernels do not take) must
+    be served by the per-timestep kernels, with the same oracle bound."""
     from oracle import native
 
     T, B, H = 12, 40, 128
