@@ -447,7 +447,11 @@ def main():
             if "lstm_bwd" in summ:
                 brackets, ms, launches, nbytes, tsteps = summ["lstm_bwd"]
                 resident = launches < 1.5 * brackets
-                kname = "lstm_bwd_resident" if resident else "lstm_bwd_step_mfma"
+                lib_ = _lib.lib()
+                split_on = bool(lib_.caiman_lstm_resident_bwd_split(1))
+                lib_.caiman_lstm_resident_bwd_split(int(split_on))
+                kname = (("lstm_bwd_resident2_bt" if args.batch > 32 else "lstm_bwd_resident2") if split_on else "lstm_bwd_resident") \
+                    if resident else "lstm_bwd_step_mfma"
                 achieved = nbytes / (ms * 1e-3) / 1e9
                 # The resident kernel is a chain of dependent timesteps, not a stream: the figure that moves is the time per
                 # timestep against the MFMA floor of one timestep (8*B*H^2 FLOP of one layer on its 32 CUs' matrix cores).
@@ -476,7 +480,7 @@ def main():
             if "loss_bwd" in summ:
                 n_launch, ms = summ["loss_bwd"][0], summ["loss_bwd"][1]
                 alg = cells * N_CLASSES * 2 * 2  # V*s read + V*s write per lattice cell
-                out["roofline_loss_bwd"] = {"kernel": "loss_bwd_kernel", "bound": "hbm",
+                out["roofline_loss_bwd"] = {"kernel": "loss_bwd_colsum_kernel (+ row descriptors + partial-sum reduction: fused joint_fc bias gradient)", "bound": "hbm",
                                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                             "avg_launch_ms": ms / n_launch, "launches": n_launch}
