@@ -20,6 +20,7 @@
 // A generic scalar kernel covers f32 / f64 and sizes the MFMA tiles do not divide.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -549,6 +550,21 @@ struct FastAct<false> : Act<float, false> {
 // collective waits for the slowest rank.
 constexpr int kResTimeoutTicks = 500000000;
 constexpr int kResCounterStride = 32;       // one 128-byte line per slot counter
+constexpr int kRes2CtrPerSlot = 12;          // 2-D split backward kernel: qc[4] + gc[8] per slot
+constexpr int kResMaxTiles = 4;              // batch-tile kernels: 32-row tiles per workgroup
+// a launch's counter block (+ the abort word): 12 counters per slot for the 2-D split backward kernel, one for the others
+constexpr size_t kResSyncBytes = (size_t)(kMaxSlots * kRes2CtrPerSlot + 1) * kResCounterStride * sizeof(unsigned);
+constexpr size_t kResSyncBytesBT = (size_t)(kMaxSlots * kResMaxTiles * 12 + 1) * kResCounterStride * sizeof(unsigned);
+// A launch's counters start at zero.  A memset in front of every resident launch cost ~90 fill commands per step
+// (4 us each plus the command-processor gap around them); instead workgroup (0, 0) of every resident launch clears the
+// block that the launch HALF A POOL LATER will use.  Resident launches are totally ordered (res_begin), so that block
+// belongs to no launch in flight: its last user finished half a pool ago and its next user starts after this launch
+// has completed (the kernel-end release makes the stores visible to it).
+__device__ inline void res_scrub(unsigned* blk, int words) {
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < words; i += blockDim.x)
+      __hip_atomic_store(blk + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ bool res_wait(unsigned* cnt, unsigned target, unsigned* fail_dev, unsigned* fail_host) {
   const long long t0 = wall_clock64();
@@ -599,7 +615,7 @@ __device__ __forceinline__ void res_store16(const V& val, __amdgpu_buffer_rsrc_t
 // (wait for the peers | h into LDS | MFMA + cell update | drain of the stores + barrier) and the timestep count.
 constexpr int kResProfFwd = 2, kResProfBwd = 8;
 template <typename T, bool HARD, int NKS, bool PROF>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
+__global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host, unsigned* scrub) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
   constexpr int H = NKS * 32, LDH = H + 8;   // LDS row pitch: +16 bytes keeps the 16 lanes of a b128 read on distinct banks
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
 
   const int slot = blockIdx.y, j = blockIdx.x;
   const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
   if (nsteps <= 0) return;
   const int nwg = gridDim.x;
   unsigned* cnt = sync + slot * kResCounterStride;
@@ -826,10 +843,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
 // re-read from the row the workgroup wrote a timestep earlier (rounded to the storage type there, exactly what the
 // single-tile kernel keeps in its registers).  Per-timestep launches at B = 128 spend 16.4 ms per training step in the
 // forward recurrence; this kernel ~ 4 tiles x 3.6 us x 560 timesteps.
-constexpr int kResMaxTiles = 4;
-constexpr size_t kResSyncBytesBT = (size_t)(kMaxSlots * kResMaxTiles * 12 + 1) * kResCounterStride * sizeof(unsigned);
 template <typename T, bool HARD, int NKS>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
+__global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host, unsigned* scrub) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
   constexpr int H = NKS * 32, LDH = H + 8;
@@ -841,6 +856,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, in
 
   const int slot = blockIdx.y, j = blockIdx.x;
   const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytesBT / sizeof(unsigned)));
   if (nsteps <= 0) return;
   const int nwg = gridDim.x;
   const int ntiles = (B + 31) / 32;
@@ -1070,7 +1086,7 @@ struct BwdResGeom {
 };
 
 template <typename T, bool HARD, int NKS, bool PROF>
-__global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host) {
+__global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host, unsigned* scrub) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
   using G = BwdResGeom<NKS>;
@@ -1092,6 +1108,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
 
   const int slot = blockIdx.y, j = blockIdx.x;
   const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
   if (nsteps <= 0) return;
   const int nwg = gridDim.x;
   unsigned* cnt = sync + slot * kResCounterStride;
@@ -1376,13 +1393,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
 // only by the XCDs that need it (2.1x -> ~1x HBM-side traffic).  Placement only changes the speed.
 // Sums are fp32 throughout: four K-quarter partials added in a fixed order (deterministic run to run).
 // ===========================================================================
-constexpr int kRes2CtrPerSlot = 12;                     // qc[4] + gc[8]
 constexpr size_t kRes2PartialFloatsPerSlot = (size_t)2 * 8 * 16 * 1024;   // [parity][jq <= 8][dst 4][src 4][32 x 32]
 constexpr int kResProfBwd2 = 16;                        // fail_host words [16, 24): six phase sums, unused, timesteps
 
 template <typename T, bool HARD, int NKS, bool PROF>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host,
-                                                             float* pws) {
+                                                             float* pws, unsigned* scrub) {
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
   constexpr int H = NKS * 32;
@@ -1399,6 +1415,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
 
   const int slot = blockIdx.y, bx = blockIdx.x;
   const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
   if (nsteps <= 0) return;
   const int kq = bx & 3, jq = bx >> 2;
   unsigned* qc_wait = sync + (slot * kRes2CtrPerSlot + kq) * kResCounterStride;
@@ -1668,7 +1685,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
 // all tiles in registers.
 template <typename T, bool HARD, int NKS>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host,
-                                                                float* pws) {
+                                                                float* pws, unsigned* scrub) {
   constexpr bool PROF = false;
   using frag = typename frag8<T>::type;
   using g4 = __attribute__((ext_vector_type(4))) T;
@@ -1686,6 +1703,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
 
   const int slot = blockIdx.y, bx = blockIdx.x;
   const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytesBT / sizeof(unsigned)));
   if (nsteps <= 0) return;
   const int kq = bx & 3, jq = bx >> 2;
   const int ntiles = (B + 31) / 32;
@@ -2033,8 +2051,6 @@ int launch_bwd_waves(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t 
 
 // ---- resident launch state: per-device pool of zeroed counter blocks + a host-visible failure word ----
 constexpr int kResPool = 32;
-// a launch's counter block: the 2-D split backward kernel needs 12 counters per slot, the others one; + the abort word
-constexpr size_t kResSyncBytes = (size_t)(kMaxSlots * kRes2CtrPerSlot + 1) * kResCounterStride * sizeof(unsigned);
 struct ResState {
   unsigned* sync[kResPool] = {};
   unsigned* fail_host = nullptr;
@@ -2059,10 +2075,14 @@ std::atomic<int> g_res_bwd_split{1};   // 2-D split backward kernel where the sh
 std::atomic<long long> g_res_launches{0};
 
 // counter block for one launch; orders the launch behind a resident launch still running on another stream
-unsigned* res_begin(ResState* st, hipStream_t s) {
+unsigned* res_begin(ResState* st, hipStream_t s, unsigned** scrub) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   unsigned* sync = st->sync[st->next];
+  *scrub = st->sync[(st->next + kResPool / 2) % kResPool];   // res_scrub: cleared by this launch for the one half a pool later
   st->next = (st->next + 1) % kResPool;
+  // measurement aid: the round-1 behaviour (a fill command in front of every launch) for an A/B on one box
+  static const bool memset_too = std::getenv("CAIMAN_LSTM_RESIDENT_MEMSET") != nullptr;
+  if (memset_too) (void)hipMemsetAsync(sync, 0, kResSyncBytes, s);
   if (st->has_last && st->last_stream != s) (void)hipStreamWaitEvent(s, st->done, 0);
   return sync;
 }
@@ -2089,7 +2109,9 @@ ResState* res_state() {
     if (hipMalloc(reinterpret_cast<void**>(&st.partials), kMaxSlots * kRes2PartialFloatsPerSlot * sizeof(float)) != hipSuccess)
       return nullptr;
     for (int i = 0; i < kResPool; ++i)
-      if (hipMalloc(reinterpret_cast<void**>(&st.sync[i]), kResSyncBytes) != hipSuccess) return nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&st.sync[i]), kResSyncBytes) != hipSuccess ||
+          hipMemset(st.sync[i], 0, kResSyncBytes) != hipSuccess)
+        return nullptr;
     if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) return nullptr;
     st.ok = true;
   }
@@ -2111,8 +2133,8 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
-  unsigned* sync = res_begin(st, s);
-  if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  unsigned* scrub = nullptr;
+  unsigned* sync = res_begin(st, s, &scrub);
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
@@ -2129,7 +2151,7 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
       }                                                                                                              \
       attr_done = true;                                                                                              \
     }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, scrub);                                \
   } while (0)
   switch (nks) {
     case 2: CAIMAN_RES(2); break;
@@ -2170,8 +2192,8 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
-  unsigned* sync = res_begin(st, s);
-  if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  unsigned* scrub = nullptr;
+  unsigned* sync = res_begin(st, s, &scrub);
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = res_bwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
@@ -2188,7 +2210,7 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
       }                                                                                                              \
       attr_done = true;                                                                                              \
     }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, scrub);                                \
   } while (0)
   switch (nks) {
     case 2: CAIMAN_RES(2); break;
@@ -2222,17 +2244,17 @@ bool try_bwd_resident2(const BwdSlots<T>& w, int n_slots, int n_launches, int64_
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
-  unsigned* sync = res_begin(st, s);
-  if (hipMemsetAsync(sync, 0, kResSyncBytes, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  unsigned* scrub = nullptr;
+  unsigned* sync = res_begin(st, s, &scrub);
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
   const bool prof = g_res_mode.load(std::memory_order_relaxed) == 2;
 #define CAIMAN_RES2(NKV)                                                                                             \
   do {                                                                                                               \
     if (prof) hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, true>), grid, dim3(256), lds, s, w, (int)B, sync,  \
-                                 st->fail_host, st->partials);                                                      \
+                                 st->fail_host, st->partials, scrub);                                                      \
     else hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, false>), grid, dim3(256), lds, s, w, (int)B, sync,     \
-                            st->fail_host, st->partials);                                                           \
+                            st->fail_host, st->partials, scrub);                                                           \
   } while (0)
   if (nks == 16) CAIMAN_RES2(16); else CAIMAN_RES2(32);
 #undef CAIMAN_RES2
@@ -2246,13 +2268,16 @@ bool res_bt_ready(ResState* st) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   if (st->partials_bt) return true;
   for (int i = 0; i < kResPool; ++i)
-    if (hipMalloc(reinterpret_cast<void**>(&st->sync_bt[i]), kResSyncBytesBT) != hipSuccess) return false;
+    if (hipMalloc(reinterpret_cast<void**>(&st->sync_bt[i]), kResSyncBytesBT) != hipSuccess ||
+        hipMemset(st->sync_bt[i], 0, kResSyncBytesBT) != hipSuccess)
+      return false;
   return hipMalloc(reinterpret_cast<void**>(&st->partials_bt),
                    (size_t)kMaxSlots * kResMaxTiles * kRes2PartialFloatsPerSlot * sizeof(float)) == hipSuccess;
 }
-unsigned* res_begin_bt(ResState* st, hipStream_t s) {
+unsigned* res_begin_bt(ResState* st, hipStream_t s, unsigned** scrub) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   unsigned* sync = st->sync_bt[st->next_bt];
+  *scrub = st->sync_bt[(st->next_bt + kResPool / 2) % kResPool];
   st->next_bt = (st->next_bt + 1) % kResPool;
   if (st->has_last && st->last_stream != s) (void)hipStreamWaitEvent(s, st->done, 0);
   return sync;
@@ -2269,8 +2294,8 @@ bool try_fwd_resident_bt(const FwdSlots<T>& w, int n_slots, int n_launches, int6
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus || !res_bt_ready(st)) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
-  unsigned* sync = res_begin_bt(st, s);
-  if (hipMemsetAsync(sync, 0, kResSyncBytesBT, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  unsigned* scrub = nullptr;
+  unsigned* sync = res_begin_bt(st, s, &scrub);
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RESBT(NKV)                                                                                            \
@@ -2285,7 +2310,7 @@ bool try_fwd_resident_bt(const FwdSlots<T>& w, int n_slots, int n_launches, int6
       }                                                                                                              \
       attr_set[st->dev] = true;                                                                                      \
     }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host);                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, scrub);                                \
   } while (0)
   if (nks == 8) CAIMAN_RESBT(8); else if (nks == 16) CAIMAN_RESBT(16); else CAIMAN_RESBT(32);
 #undef CAIMAN_RESBT
@@ -2309,14 +2334,14 @@ bool try_bwd_resident2_bt(const BwdSlots<T>& w, int n_slots, int n_launches, int
   ResState* st = res_state();
   if (!st || (int64_t)n_slots * nks > st->cus || !res_bt_ready(st)) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
-  unsigned* sync = res_begin_bt(st, s);
-  if (hipMemsetAsync(sync, 0, kResSyncBytesBT, s) != hipSuccess) { *err = check_launch("lstm resident memset"); return true; }
+  unsigned* scrub = nullptr;
+  unsigned* sync = res_begin_bt(st, s, &scrub);
   const dim3 grid((unsigned)nks, (unsigned)n_slots);
   const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
   if (nks == 16)
-    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt);
+    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
   else
-    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt);
+    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
   res_end(st, s);
   *err = check_launch("lstm resident backward (2-D split, batch tiles)");
   return true;
@@ -2494,6 +2519,14 @@ extern "C" int caiman_lstm_resident_set_failures(int count) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   volatile unsigned* f = st->fail_host;
   const int prev = (int)f[0];
+  if (count <= 0 && prev != 0) {
+    // an aborted launch leaves its counter block (and the block it was scrubbing) in an unknown state
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < kResPool; ++i) {
+      (void)hipMemset(st->sync[i], 0, kResSyncBytes);
+      if (st->sync_bt[i]) (void)hipMemset(st->sync_bt[i], 0, kResSyncBytesBT);
+    }
+  }
   f[0] = (unsigned)(count < 0 ? 0 : count);
   return prev;
 }
