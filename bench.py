@@ -376,12 +376,16 @@ def main():
     audio_s, cells = 0.0, 0
     in_flight = []   # the host may run at most two steps ahead of the device (a real loop reads the loss now and then);
     #                  unbounded run-ahead makes the allocator hold every queued step's activations at once
+    host_wait = host_issue = 0.0   # host blocked on the run-ahead limit | host queuing a step's commands
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
         if len(in_flight) >= 2:
             in_flight.pop(0).synchronize()
+        tq = time.perf_counter()
+        host_wait += tq - ts
         last_loss, a, c = step(args.warmup + i, args.warmup + i)
+        host_issue += time.perf_counter() - tq
         done = torch.cuda.Event()
         done.record(main_stream if args.main_priority != 0 else torch.cuda.current_stream())
         in_flight.append(done)
@@ -429,6 +433,10 @@ def main():
                                      "frontend / audio decode run outside the timed step (tools/feed_bench.py measures "
                                      "the feed separately)"},
         }
+        # how close the step is to being launch-bound: the host thread needs `issue` ms to queue a step's commands and
+        # waits `wait_for_device` ms per step for the device to catch up (run-ahead limit of two steps)
+        out["host_ms_per_step"] = {"issue": round(host_issue / args.steps * 1e3, 2),
+                                   "wait_for_device": round(host_wait / args.steps * 1e3, 2)}
         if world > 1:
             out["allreduce_exposed_ms"] = exposed_ms    # per step, max over ranks: compute stream idle in reducer.finish()
             out["gradient_exchange"] = {"bytes_per_step": int(optimizer.flat_g.numel()) * 4, "collectives_per_step": len(reducer.buckets),

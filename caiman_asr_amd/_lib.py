@@ -21,6 +21,9 @@ HEADERS = sorted(glob.glob(os.path.join(os.path.dirname(HEADER), "*.h")))
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+# per-file flags.  proj_gemm.hip: keep the MFMA accumulators in VGPRs -- left to itself the register allocator splits
+# the 128 accumulator registers of the 256 x 128 tile between VGPRs and AGPRs and moves ~150 of them per K step
+FILE_FLAGS = {"proj_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 class MissingNativeLibrary(RuntimeError):
@@ -54,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > hdr_t):
             continue
-        cmd = [HIPCC, *HIP_FLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *HIP_FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -84,6 +87,16 @@ class BwdSlot(ctypes.Structure):
                 ("parity", ctypes.c_int32), ("nsteps", ctypes.c_int32), ("has_next", ctypes.c_int32),
                 ("drop_p", ctypes.c_float), ("drop_counter", ctypes.c_uint64), ("hidden", ctypes.c_int32),
                 ("reserved", ctypes.c_int32), ("dbias", ctypes.c_void_p)]
+
+class ProjProblem(ctypes.Structure):
+    """caiman_proj_problem_t (include/caiman_rnnt.h): one problem of a grouped input-projection GEMM."""
+    _fields_ = [("a", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("c", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("a_inner", ctypes.c_int32), ("a_kseg", ctypes.c_int32), ("c_inner", ctypes.c_int32),
+                ("c_nseg", ctypes.c_int32),
+                ("a_stride_outer", ctypes.c_int64), ("a_stride_inner", ctypes.c_int64), ("a_stride_seg", ctypes.c_int64),
+                ("c_stride_outer", ctypes.c_int64), ("c_stride_inner", ctypes.c_int64), ("c_stride_seg", ctypes.c_int64)]
+
 
 class BeamConfig(ctypes.Structure):
     """caiman_beam_config_t (include/caiman_beam.h)."""
@@ -116,6 +129,8 @@ _SIGS = {
     "caiman_transducer_loss_backward_colsum": (
         [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
          P, P, I64, P], ctypes.c_int),
+    "caiman_proj_gemm_supported": ([P, I32], ctypes.c_int),
+    "caiman_proj_gemm": ([P, I32, I32, I32, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_lstm_workspace_elems": ([I64, I64, I32], ctypes.c_int64),
     "caiman_lstm_prepare": ([P, P, P, P, P, I64, I64, I32, I32, I32, P], ctypes.c_int),

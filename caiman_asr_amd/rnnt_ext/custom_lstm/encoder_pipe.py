@@ -30,6 +30,45 @@ FINE = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_FINE", "1")) != 0
 # the activation tensors (layer m works one chunk behind layer m-1): issue them as ONE batched GEMM
 BMM = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_BMM", "1")) != 0
 EARLY_WGRAD = int(__import__("os").environ.get("CAIMAN_EARLY_WGRAD", "1")) != 0
+# the chunk GEMMs of a tick (input projections forward, input gradients backward) as ONE launch of the grouped
+# projection kernel (csrc/proj_gemm.hip) instead of 2-3 library calls; shapes outside its geometry keep the library path
+PROJ = int(__import__("os").environ.get("CAIMAN_PROJ_GEMM", "1")) != 0
+PROJ_TILE = int(__import__("os").environ.get("CAIMAN_PROJ_TILE", "0"))
+
+
+def _proj_ok(widths, dt):
+    """every hidden size (-> N = 4H forward, K = 4H backward) and every K of the stack fits the kernel's tiles."""
+    return PROJ and dt in (torch.float16, torch.bfloat16) and all(w % 128 == 0 for w in widths)
+
+
+_PROJ_DT = None
+
+
+def _proj_plan(per_tick):
+    """per_tick: for every tick a list of caiman_proj_problem_t field tuples.  -> (numpy image of all of them, [(first, count)]
+    per tick).  One array for the whole pass: building ctypes structures tick by tick cost 50 us of host time per tick,
+    which the pipeline (a launch every ~200 us) does not have to spare."""
+    global _PROJ_DT
+    import numpy as np
+
+    if _PROJ_DT is None:
+        _PROJ_DT = np.dtype([(n_, "<u8") for n_ in ("a", "w", "bias", "c")] +
+                            [(n_, "<i4") for n_ in ("M", "N", "K", "a_inner", "a_kseg", "c_inner", "c_nseg", "_pad")] +
+                            [(n_, "<i8") for n_ in ("a_so", "a_si", "a_ss", "c_so", "c_si", "c_ss")])
+        assert _PROJ_DT.itemsize == ctypes.sizeof(_lib.ProjProblem)
+    rows, ranges = [], []
+    for probs in per_tick:
+        probs.sort(key=lambda r: -r[6])     # longest K first: the long tiles start first, the short ones fill in
+        ranges.append((len(rows), len(probs)))
+        rows += probs
+    return np.array(rows, dtype=_PROJ_DT) if rows else None, ranges
+
+
+def _proj_launch(lib, plan, rng, tag, st):
+    first, count = rng
+    base = plan.ctypes.data
+    for i in range(0, count, 8):
+        _lib.check(lib.caiman_proj_gemm(base + (first + i) * _PROJ_DT.itemsize, min(8, count - i), tag, PROJ_TILE, st))
 
 
 def _skewed(t, first_layer, first_t0, count, n, B, width, chunk, row_offset=0):
@@ -115,6 +154,10 @@ class EncoderPipeFunction(torch.autograd.Function):
         Rp = [R.to(dt).contiguous() for R in Rs]
         Wp = [_perm_cast_t(Ws[l], Hl[l], dt) for l in range(L)]   # [K, 4H]
         bias = [_perm_cast(bWs[l] + bRs[l], Hl[l], dt) for l in range(L)]
+        # grouped projection kernel: wants [4H, K] (K contiguous) images of the layers that take a chunk GEMM per tick
+        use_proj = _proj_ok(set(Hl) | {f * H}, dt)
+        Wn = [(_perm_cast(Ws[l], Hl[l], dt) if (use_proj and l != 0 and l != Le) else None) for l in range(L)]
+        es = torch.empty((), dtype=dt).element_size()
         Ga = torch.empty((La, T1, B, 4 * H), dtype=dt, device=dev)
         Gb = torch.empty((Lb, T2, B, 4 * H), dtype=dt, device=dev)
         torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=Ga[0].view(T1 * B, 4 * H))
@@ -173,12 +216,41 @@ class EncoderPipeFunction(torch.autograd.Function):
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), False) if h else 0 for h in Hl]
-        Wt_post = torch.stack([Wp[l] for l in range(La + 1, Le)]) if (BMM and Lb > 2) else None      # [Lb-1, H, 4H]
+        Wt_post = torch.stack([Wp[l] for l in range(La + 1, Le)]) if (BMM and Lb > 2 and not use_proj) else None      # [Lb-1, H, 4H]
         b_post = torch.stack([bias[l] for l in range(La + 1, Le)]).unsqueeze(1) if Wt_post is not None else None
-        for tick in _schedule(nA, nB, La, Lb, f, nP, Lp):
+        sched = _schedule(nA, nB, La, Lb, f, nP, Lp)
+        if use_proj:
+            gp = [g_.data_ptr() for g_ in G]
+            # input rows of layer l: the (masked) output of the layer below, one row block [B, H] per timestep
+            srcp = [None if (l == 0 or l == Le) else (YM[l - 1].data_ptr() if pl[l - 1] > 0.0 else Y[l - 1][1].data_ptr())
+                    for l in range(L)]
+            wnp = [w_.data_ptr() if w_ is not None else None for w_ in Wn]
+            bp_ = [b_.data_ptr() for b_ in bias]
+            per_tick = []
+            for tick in sched:
+                probs = []
+                for l, k in tick:
+                    if l == 0 or l == Le:
+                        continue
+                    t0, n = k * CHl[l], min(CHl[l], Tl[l] - k * CHl[l])
+                    hl = Hl[l]
+                    c = gp[l] + t0 * B * 4 * hl * es
+                    if l == La:      # StackTime: row (t, b) = frames f*t .. f*t + f - 1 of the top pre layer, side by side
+                        probs.append((srcp[l] + f * t0 * B * H * es, wnp[l], bp_[l], c, n * B, 4 * hl, f * H,
+                                      B, H, n * B, 4 * hl, 0, f * B * H, H, B * H, 0, 4 * hl, 0))
+                    else:
+                        probs.append((srcp[l] + t0 * B * hl * es, wnp[l], bp_[l], c, n * B, 4 * hl, hl,
+                                      n * B, hl, n * B, 4 * hl, 0, 0, hl, 0, 0, 4 * hl, 0))
+                per_tick.append(probs)
+            plan, ranges = _proj_plan(per_tick)
+        for ti, tick in enumerate(sched):
             slots, nbytes = [], 0
             batched = set()
-            if Wt_post is not None:   # post layers La+1.. with a full chunk this tick: consecutive layers, chunk index falling by one
+            if use_proj:
+                if ranges[ti][1]:
+                    _proj_launch(lib, plan, ranges[ti], tag, st)
+                batched = {l for l, _ in tick}
+            elif Wt_post is not None:   # post layers La+1.. with a full chunk this tick: consecutive layers, chunk index falling by one
                 grp = [(l, k) for l, k in tick if La < l < Le and Tl[l] - k * CHb >= CHb]
                 if len(grp) >= 2 and all(grp[i + 1][0] == grp[i][0] + 1 and grp[i + 1][1] == grp[i][1] - 1 for i in range(len(grp) - 1)):
                     l0, k0 = grp[0]
@@ -296,11 +368,45 @@ class EncoderPipeFunction(torch.autograd.Function):
         fused_db = all(lib.caiman_lstm_resident_would_run(B, h, min(8, L)) for h in set(Hl))
         dbias = torch.zeros((L, 4 * max(Hl)), dtype=torch.float32, device=dev) if fused_db else None
         boundary_done = set()   # post chunks whose input gradient has been un-stacked into delta[La-1]
-        W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]).transpose(1, 2) if (BMM and Lb > 2) else None   # views [Lb-1, 4H, H]
-        for tick in reversed(_schedule(nA, nB, La, Lb, f, nP, Lp)):
+        use_proj = _proj_ok(set(Hl) | {f * H}, dt)
+        W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]).transpose(1, 2) if (BMM and Lb > 2 and not use_proj) else None   # views [Lb-1, 4H, H]
+        sched = list(reversed(_schedule(nA, nB, La, Lb, f, nP, Lp)))
+        if use_proj:
+            # input gradients of a tick's chunks: delta_l = dG_{l+1} @ W_{l+1} (W stored [K_in, 4H] = the kernel's [N][K]
+            # operand), the top pre layer's through StackTime (the columns of a row scatter to f frames)
+            es = Ga.element_size()
+            dgp = [g_.data_ptr() for g_ in dG]
+            dlp = [d_.data_ptr() for d_ in delta]
+            wpp = [w_.data_ptr() for w_ in Wp]
+            per_tick = []
+            for tick in sched:
+                probs = []
+                for l, k in reversed(tick):
+                    if l in top:
+                        continue
+                    t0, n = k * CHl[l], min(CHl[l], Tl[l] - k * CHl[l])
+                    hl = Hl[l]
+                    if l == La - 1:
+                        j = t0 // (f * CHb)
+                        if j in boundary_done:
+                            continue
+                        boundary_done.add(j)
+                        p0, pn = j * CHb, min(CHb, T2 - j * CHb)
+                        probs.append((dgp[La] + p0 * B * 4 * H * es, wpp[La], 0, dlp[l] + f * p0 * B * H * es, pn * B, f * H, 4 * H,
+                                      pn * B, 4 * H, B, H, 0, 0, 4 * H, 0, f * B * H, H, B * H))
+                    else:
+                        probs.append((dgp[l + 1] + t0 * B * 4 * hl * es, wpp[l + 1], 0, dlp[l] + t0 * B * hl * es, n * B, hl, 4 * hl,
+                                      n * B, 4 * hl, n * B, hl, 0, 0, 4 * hl, 0, 0, hl, 0))
+                per_tick.append(probs)
+            plan, ranges = _proj_plan(per_tick)
+        for ti, tick in enumerate(sched):
             slots, nbytes = [], 0
             batched = set()
-            if W_post is not None:   # delta of post layers La..Le-2 with a full chunk: dG of the layer above times its W_ih
+            if use_proj:
+                if ranges[ti][1]:
+                    _proj_launch(lib, plan, ranges[ti], tag, st)
+                batched = {l for l, _ in tick}
+            elif W_post is not None:   # delta of post layers La..Le-2 with a full chunk: dG of the layer above times its W_ih
                 grp = [(l, k) for l, k in tick if La <= l < Le - 1 and Tl[l] - k * CHb >= CHb]
                 if len(grp) >= 2 and all(grp[i + 1][0] == grp[i][0] + 1 and grp[i + 1][1] == grp[i][1] - 1 for i in range(len(grp) - 1)):
                     l0, k0 = grp[0]
@@ -312,7 +418,9 @@ class EncoderPipeFunction(torch.autograd.Function):
             for l, k in reversed(tick):
                 t0, n = k * CHl[l], min(CHl[l], Tl[l] - k * CHl[l])
                 thi, hl, row = t0 + n - 1, Hl[l], B * Hl[l]
-                if l == La - 1:      # top pre layer: gradient arrives through StackTime from post layer 0
+                if l in batched:
+                    pass             # the grouped projection kernel has written delta[l] of this chunk
+                elif l == La - 1:    # top pre layer: gradient arrives through StackTime from post layer 0
                     j = t0 // (f * CHb)
                     if j not in boundary_done:
                         boundary_done.add(j)

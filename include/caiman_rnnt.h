@@ -241,6 +241,35 @@ int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots);
 int caiman_lstm_resident_profile(uint32_t* out10);
 
 /* ------------------------------------------------------------------------- *
+ * Grouped input-projection GEMM of the layer-pipelined LSTM stacks (csrc/proj_gemm.hip) — replaces, chunk by chunk,
+ *   gates = torch.addmm(bias, x, W_ih.t())          training/lib/src/rnnt_ext/custom_lstm/lstm.py:51-55
+ *   dx    = dG @ W_ih  (autograd of the same call)   and the StackTime gather / scatter around the first post_rnn
+ *                                                    layer (training/caiman_asr_train/rnnt/model.py:314-342)
+ * for all layers that work in one pipeline tick, in ONE launch:  C[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]).
+ * W is row-major [N][K]; A and C rows are addressed as (outer, inner, segment):
+ *   A(m, k) at a + (m / a_inner) * a_stride_outer + (m % a_inner) * a_stride_inner + (k / a_kseg) * a_stride_seg + k % a_kseg
+ *   C(m, n) at c + (m / c_inner) * c_stride_outer + (m % c_inner) * c_stride_inner + (n / c_nseg) * c_stride_seg + n % c_nseg
+ * (strides in elements; a plain row-major matrix: inner = M, stride_inner = leading dimension, kseg = K / nseg = N).
+ * bf16 / f16 only; N % 128 == 0, K % 128 == 0, a_kseg % 64 == 0, c_nseg % 16 == 0, 16-byte aligned operand rows:
+ * caiman_proj_gemm_supported() tells; caiman_proj_gemm() returns CAIMAN_ERR_INVALID for anything else (the caller then
+ * keeps the library GEMM).  Put the problems with the longest K first.  tile: 0 = choose, 1 = 256 x 128 tiles with two LDS stages, 2 = 128 x 128,
+ * 3 = 256 x 128 with three stages (two in flight).
+ * ------------------------------------------------------------------------- */
+#define CAIMAN_PROJ_MAX_PROBLEMS 8
+typedef struct {
+  const void* a;
+  const void* w;
+  const void* bias; /* [N] in the operand dtype, or NULL */
+  void* c;
+  int32_t M, N, K;
+  int32_t a_inner, a_kseg, c_inner, c_nseg;
+  int64_t a_stride_outer, a_stride_inner, a_stride_seg;
+  int64_t c_stride_outer, c_stride_inner, c_stride_seg;
+} caiman_proj_problem_t;
+int caiman_proj_gemm_supported(const caiman_proj_problem_t* problem, int dtype);
+int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n_problems, int dtype, int tile, caiman_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
  * vendored; call sites training/caiman_asr_train/rnnt/model.py:228-238,425-434; CPU
  * equivalent `torch_transducer_joint` + `relu_drop`, model.py:441-447,224).
