@@ -97,3 +97,59 @@ def test_mfma_lstm_state_passing_and_schedule_invariance_at_base_width():
     assert torch.allclose(ref.float(), full.float(), atol=1e-2 * ref.float().abs().max().item())
     assert torch.allclose(cr.float(), cf.float(), atol=1e-2 * cr.float().abs().max().item())
     assert ah.shape == (L, T, B, H) and torch.equal(ah[-1], full)
+
+
+def test_base_85m_step_at_128_utterances_per_gpu_runs_on_the_batch_tile_kernels():
+    """BASELINE.json configs[2] per-GPU shape: base-85M, B = 128 (short utterances keep the lattice small), one bf16
+    training step.  The recurrence must be served by the weight-resident batch-tile kernels (4 tiles of 32 rows), and the
+    step must agree with the same step on the per-timestep kernels to the storage type's resolution."""
+    import json
+    import os
+
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, get_packing_meta_data
+    from caiman_asr_amd.rnnt.model import RNNT
+
+    lib = _lib.lib()
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rnnt_cfg_base.json")))
+    cfg = dict(cfg, enc_dropout=0.0, pred_dropout=0.0, joint_dropout=0.0)
+    V, B = 8704, 128
+    torch.manual_seed(3)
+    m = RNNT(n_classes=V, **cfg).to(DEV).train()
+    rng = np.random.default_rng(1)
+    T1 = 40
+    x_lens = rng.integers(20, T1 + 1, size=B)
+    x_lens[0] = T1
+    y_lens = rng.integers(2, 7, size=B)
+    x = torch.tensor(rng.standard_normal((T1, B, 240)).astype(np.float32), device=DEV)
+    y = torch.tensor(rng.integers(0, V - 1, size=(B, 6)), device=DEV)
+    xl, yl = torch.tensor(x_lens), torch.tensor(y_lens)
+    meta = get_packing_meta_data(xl, yl, 2, device=DEV)
+    loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+    names = ("encoder.pre_rnn.lstm.weight_hh_l0", "encoder.post_rnn.lstm.weight_ih_l0", "prediction.dec_rnn.lstm.weight_hh_l1",
+             "joint_net.2.weight")
+    out = []
+    for mode in (1, 0):
+        prev = lib.caiman_lstm_resident_mode(mode)
+        try:
+            n0 = lib.caiman_lstm_resident_launches()
+            m.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                logits, out_lens, _ = m(x, xl.to(DEV), y, yl.to(DEV), batch_offset=meta["batch_offset"],
+                                        packed_batch=meta["packed_batch"])
+                loss = loss_fn(logits, out_lens, y, yl.to(DEV), meta["batch_offset"], meta["max_f_len"])
+            loss.backward()
+            torch.cuda.synchronize()
+            launches = lib.caiman_lstm_resident_launches() - n0
+            grads = {n: p.grad.float().clone() for n, p in m.named_parameters() if n in names}
+            assert len(grads) == len(names)
+            out.append((float(loss.detach()), grads, launches))
+        finally:
+            lib.caiman_lstm_resident_mode(prev)
+    (l1, g1, n1), (l0, g0, n0_) = out
+    assert n1 > 0 and n0_ == 0, (n1, n0_)
+    assert lib.caiman_lstm_resident_failures() == 0
+    assert np.isfinite(l1) and abs(l1 - l0) <= 5e-3 * abs(l0), (l1, l0)
+    for n in names:
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g1[n] - g0[n]).abs().max()) <= 6e-2 * scale, n

@@ -242,18 +242,19 @@ def test_state_passing_through_the_pipelined_stacks_equals_the_concatenated_run(
     assert rsp_end_step(state, False, 5, Namespace(rsp_seq_len_freq=[1, 1], rsp_delay=10), 3)[0] is None
 
 
-def test_base_85m_on_baseline_config0_matches_the_oracle():
+@pytest.mark.parametrize("size,V", [("base", 8704), ("large", 17408)])
+def test_base_85m_on_baseline_config0_matches_the_oracle(size, V):
     """BASELINE.json configs[0]: base-85M, 2 synthetic 1 s utterances (feats [34, 2, 240], U = [5, 3]), forward + RNN-T
     loss + backward: the HIP path in fp32 and under bf16 autocast against oracle.model.loss_and_grads (fp32 network,
     f64 loss).  fp32 tolerance as stated in SURVEY section 8(d).1 (loss 1e-5 relative); bf16: storage resolution through
-    8 + 2 LSTM layers."""
+    8 + 2 LSTM layers.  "large": the same workload on the 196 M model of configs[3] (H = 1536 encoder on the
+    per-timestep kernels, H = 768 prediction network, V = 17 408)."""
     from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, get_packing_meta_data
     from caiman_asr_amd.rnnt.model import RNNT
     from oracle import model as omodel
 
-    cfg = json.load(open(os.path.join(GOLD, "rnnt_cfg_base.json")))
+    cfg = json.load(open(os.path.join(GOLD, f"rnnt_cfg_{size}.json")))
     cfg = dict(cfg, enc_dropout=0.0, pred_dropout=0.0, joint_dropout=0.0)
-    V = 8704
     torch.manual_seed(11)
     m = RNNT(n_classes=V, **cfg).to(DEV)
     m.train()
