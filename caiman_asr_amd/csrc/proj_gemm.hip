@@ -47,12 +47,13 @@ struct ProjBatch {
   int n;
 };
 
-template <typename T, int BM, int BN, int NS>
-__global__ __launch_bounds__(256, 1) void proj_gemm_kernel(ProjBatch pb) {
+template <typename T, int BM, int BN, int NS, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void proj_gemm_kernel(ProjBatch pb) {
   using frag = typename pfrag<T>::type;
   constexpr int BK = 64;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int ABLK = BM / 32, WBLK = BN / 32;   // 8-row blocks (1 KB, one DMA instruction) per wave and operand
+  constexpr int WGM = NW / 2;                     // waves along M; two along N
+  constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int ABLK = BM / 8 / NW, WBLK = BN / 8 / NW;   // 8-row blocks (1 KB, one DMA instruction) per wave and operand
   __shared__ __attribute__((aligned(1024))) T lA0[BM * BK], lA1[BM * BK], lW0[BN * BK], lW1[BN * BK];
   __shared__ __attribute__((aligned(1024))) T lA2[NS == 3 ? BM * BK : 8], lW2[NS == 3 ? BN * BK : 8];   // third stage
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void proj_gemm_kernel(ProjBatch pb) {
   unsigned a_off[ABLK], w_off[WBLK];
 #pragma unroll
   for (int i = 0; i < ABLK; ++i) {
-    const int rt = (wave + 4 * i) * 8 + (lane >> 3);
+    const int rt = (wave + NW * i) * 8 + (lane >> 3);
     const int m = m0 + rt < M ? m0 + rt : M - 1;          // rows past M re-read the last row; never stored
     const int q = (lane & 7) ^ ((rt >> 1) & 7);
     a_off[i] = (unsigned)(((int64_t)(m / P.a_inner - m0 / P.a_inner) * P.a_stride_outer +
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void proj_gemm_kernel(ProjBatch pb) {
   const char* a_base = reinterpret_cast<const char*>(Ap + (int64_t)(m0 / P.a_inner) * P.a_stride_outer);
 #pragma unroll
   for (int i = 0; i < WBLK; ++i) {
-    const int rt = (wave + 4 * i) * 8 + (lane >> 3);
+    const int rt = (wave + NW * i) * 8 + (lane >> 3);
     const int q = (lane & 7) ^ ((rt >> 1) & 7);
     w_off[i] = (unsigned)((rt * K + q * 8) * (int)sizeof(T));
   }
@@ -99,11 +100,11 @@ __global__ __launch_bounds__(256, 1) void proj_gemm_kernel(ProjBatch pb) {
 #pragma unroll
     for (int i = 0; i < ABLK; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + a_off[i]),
-                                       (__attribute__((address_space(3))) void*)(lA + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lA + (wave + NW * i) * 8 * BK), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < WBLK; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + w_off[i]),
-                                       (__attribute__((address_space(3))) void*)(lW + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lW + (wave + NW * i) * 8 * BK), 16, 0, 0);
   };
 
   const int wm = wave >> 1, wn = wave & 1;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void proj_gemm_kernel(ProjBatch pb) {
     // step: behind it every wave's share of stage ks has landed (each waited for its own DMAs, all but the youngest
     // stage's) and every wave has finished multiplying stage ks - 1, whose buffer the DMAs of stage ks + 2 now overwrite.
     // A bare s_barrier: __syncthreads() carries a fence that would drain the DMAs in flight.
-    static_assert(ABLK + WBLK == 12 || ABLK + WBLK == 8, "vmcnt immediates below");
+    static_assert(ABLK + WBLK == 12 || ABLK + WBLK == 8 || NS == 2, "vmcnt immediates below");
     auto phase = [&](const T* cA, const T* cW, T* nA, T* nW, int ks) {
       // s_waitcnt through the builtin (the compiler's own wait-count bookkeeping sees it; an asm wait it would follow with
       // a vmcnt(0) of its own before the first LDS read).  simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 0 << 8.
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void proj_gemm_kernel(ProjBatch pb) {
   }
 }
 
-template <typename T, int BM, int BN, int NS>
+template <typename T, int BM, int BN, int NS, int NW>
 int launch_proj(const caiman_proj_problem_t* problems, int n, hipStream_t s) {
   ProjBatch pb;
   pb.n = n;
@@ -237,7 +238,7 @@ int launch_proj(const caiman_proj_problem_t* problems, int n, hipStream_t s) {
   for (int i = n; i <= kProjMax; ++i) pb.tile_begin[i] = tiles;
   for (int i = n; i < kProjMax; ++i) { pb.p[i] = problems[0]; pb.tiles_n[i] = 1; }
   if (tiles == 0) return CAIMAN_OK;
-  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, NS>), dim3((unsigned)tiles), dim3(256), 0, s, pb);
+  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, NS, NW>), dim3((unsigned)tiles), dim3(64 * NW), 0, s, pb);
   return check_launch("projection GEMM");
 }
 
@@ -268,8 +269,10 @@ extern "C" int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n, in
   // with a two-deep LDS pipeline the single workgroup per CU does not cover the load latency
   if (tile == 0) tile = 2;
   if (dtype == CAIMAN_BF16)
-    return tile == 1 ? launch_proj<bf16_t, 256, 128, 2>(problems, n, s)
-         : tile == 3 ? launch_proj<bf16_t, 256, 128, 3>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2>(problems, n, s);
-  return tile == 1 ? launch_proj<f16_t, 256, 128, 2>(problems, n, s)
-       : tile == 3 ? launch_proj<f16_t, 256, 128, 3>(problems, n, s) : launch_proj<f16_t, 128, 128, 2>(problems, n, s);
+    return tile == 1 ? launch_proj<bf16_t, 256, 128, 2, 4>(problems, n, s)
+         : tile == 3 ? launch_proj<bf16_t, 256, 128, 3, 4>(problems, n, s)
+         : tile == 4 ? launch_proj<bf16_t, 256, 128, 2, 8>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
+  return tile == 1 ? launch_proj<f16_t, 256, 128, 2, 4>(problems, n, s)
+       : tile == 3 ? launch_proj<f16_t, 256, 128, 3, 4>(problems, n, s)
+       : tile == 4 ? launch_proj<f16_t, 256, 128, 2, 8>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
 }
