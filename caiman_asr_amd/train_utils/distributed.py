@@ -70,6 +70,9 @@ class FlatGradReducer:
         # exposed_ms(); the reference reports nothing comparable, SURVEY section 8(d).3 asks for it)
         self.measure_exposed = measure_exposed and self.overlap
         self._exposed_events = []
+        # "nccl" (= RCCL) orders a collective against the stream wait() is called on; other backends (gloo: rehearsals,
+        # CPU tests) complete on the host, so their handles are waited for in finish()
+        self._stream_ordered = bool(dist.is_initialized() and self.overlap and dist.get_backend(process_group) == "nccl")
         self._guard = None       # (gradient element, failure count seen by the optimiser): see guard_handoffs()
         self._guard_bucket = None
         if self.world > 1:
@@ -148,7 +151,15 @@ class FlatGradReducer:
         if self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self._handles.append(dist.all_reduce(chunk, group=self.group, async_op=True))
+                h = dist.all_reduce(chunk, group=self.group, async_op=True)
+                if self._stream_ordered:
+                    # RCCL runs the collective on the process group's own stream; wait() does not block the host, it
+                    # makes the CURRENT stream (comm_stream) wait for that stream.  From here on comm_stream stands
+                    # for the collective, which is what overlap.fence_collectives() and finish() wait on: without it
+                    # a weight-resident LSTM launch could be placed next to a collective still in flight.
+                    h.wait()
+                else:
+                    self._handles.append(h)
         else:
             self._handles.append(dist.all_reduce(chunk, group=self.group, async_op=True))
 
