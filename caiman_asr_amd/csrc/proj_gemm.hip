@@ -264,15 +264,20 @@ extern "C" int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n, in
     CAIMAN_CHECK(caiman_proj_gemm_supported(&problems[i], dtype), "caiman_proj_gemm: problem %d is outside the kernel's geometry "
                  "(bf16 / f16; N, K %% 128 == 0; a_kseg %% 64 == 0; c_nseg %% 16 == 0; 16-byte aligned rows)", i);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // measured on the ticks of the base encoder (tools/proj_gemm_bench.py): 128 x 128 tiles, two workgroups per CU, beat
-  // 256 x 128 tiles with one (53 vs 68 us forward, 59 vs 82 us backward) although they read 1.33x the operand bytes --
-  // with a two-deep LDS pipeline the single workgroup per CU does not cover the load latency
-  if (tile == 0) tile = 2;
+  // measured on the ticks of the base encoder (tools/proj_gemm_bench.py, forward / backward tick): 128 x 128 tiles with
+  // 8 waves (wave tile 32 x 64, two workgroups = 16 waves per CU) 46 / 54 us; with 4 waves 54 / 60; 256 x 128 tiles, one
+  // workgroup per CU: 67 / 82 (4 waves, two LDS stages), 63 / 68 (three stages), 52 / 73 (8 waves).  A K step of one
+  // workgroup takes 0.55 - 1 us whatever the tile (DMA issue -> LDS reads -> MFMAs -> wait for the next stage is one
+  // serial chain per wave): more waves per CU overlap more of it, fewer operand bytes per flop do not help; 64 x 128
+  // tiles (three workgroups per CU) land on the same 53 us.
+  if (tile == 0) tile = 5;
   if (dtype == CAIMAN_BF16)
     return tile == 1 ? launch_proj<bf16_t, 256, 128, 2, 4>(problems, n, s)
          : tile == 3 ? launch_proj<bf16_t, 256, 128, 3, 4>(problems, n, s)
-         : tile == 4 ? launch_proj<bf16_t, 256, 128, 2, 8>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
+         : tile == 4 ? launch_proj<bf16_t, 256, 128, 2, 8>(problems, n, s)
+         : tile == 5 ? launch_proj<bf16_t, 128, 128, 2, 8>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
   return tile == 1 ? launch_proj<f16_t, 256, 128, 2, 4>(problems, n, s)
        : tile == 3 ? launch_proj<f16_t, 256, 128, 3, 4>(problems, n, s)
-       : tile == 4 ? launch_proj<f16_t, 256, 128, 2, 8>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
+       : tile == 4 ? launch_proj<f16_t, 256, 128, 2, 8>(problems, n, s)
+       : tile == 5 ? launch_proj<f16_t, 128, 128, 2, 8>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
 }

@@ -252,8 +252,8 @@ int caiman_lstm_resident_profile(uint32_t* out10);
  * (strides in elements; a plain row-major matrix: inner = M, stride_inner = leading dimension, kseg = K / nseg = N).
  * bf16 / f16 only; N % 128 == 0, K % 128 == 0, a_kseg % 64 == 0, c_nseg % 16 == 0, 16-byte aligned operand rows:
  * caiman_proj_gemm_supported() tells; caiman_proj_gemm() returns CAIMAN_ERR_INVALID for anything else (the caller then
- * keeps the library GEMM).  Put the problems with the longest K first.  tile: 0 = choose, 1 = 256 x 128 tiles with two LDS stages, 2 = 128 x 128,
- * 3 = 256 x 128 with three stages (two in flight).
+ * keeps the library GEMM).  Put the problems with the longest K first.  tile: 0 = choose (5), 1 = 256 x 128 tiles with two LDS stages, 2 = 128 x 128,
+ * 3 = 256 x 128 with three stages (two in flight), 4 = 256 x 128 with 8 waves, 5 = 128 x 128 with 8 waves (measurement variants).
  * ------------------------------------------------------------------------- */
 #define CAIMAN_PROJ_MAX_PROBLEMS 8
 typedef struct {
