@@ -456,8 +456,9 @@ def main():
                 brackets, ms, launches, nbytes, tsteps = summ["lstm_bwd"]
                 resident = launches < 1.5 * brackets
                 lib_ = _lib.lib()
-                split_on = bool(lib_.caiman_lstm_resident_bwd_split(1))
-                lib_.caiman_lstm_resident_bwd_split(int(split_on))
+                split_prev = lib_.caiman_lstm_resident_bwd_split(1)
+                split_on = bool(split_prev)
+                lib_.caiman_lstm_resident_bwd_split(split_prev)
                 kname = (("lstm_bwd_resident2_bt" if args.batch > 32 else "lstm_bwd_resident2") if split_on else "lstm_bwd_resident") \
                     if resident else "lstm_bwd_step_mfma"
                 achieved = nbytes / (ms * 1e-3) / 1e9
