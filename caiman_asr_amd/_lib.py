@@ -98,6 +98,13 @@ class ProjProblem(ctypes.Structure):
                 ("c_stride_outer", ctypes.c_int64), ("c_stride_inner", ctypes.c_int64), ("c_stride_seg", ctypes.c_int64)]
 
 
+class LstmImages(ctypes.Structure):
+    """caiman_lstm_images_t (include/caiman_rnnt.h): one layer of caiman_lstm_weight_images."""
+    _fields_ = [("W_ih", ctypes.c_void_p), ("W_hh", ctypes.c_void_p), ("b_ih", ctypes.c_void_p), ("b_hh", ctypes.c_void_p),
+                ("Wt", ctypes.c_void_p), ("Wn", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("Rf", ctypes.c_void_p),
+                ("Rb", ctypes.c_void_p), ("H", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
 class BeamConfig(ctypes.Structure):
     """caiman_beam_config_t (include/caiman_beam.h)."""
     _fields_ = [("blank_idx", ctypes.c_int32), ("beam_width", ctypes.c_int32),
@@ -129,6 +136,7 @@ _SIGS = {
     "caiman_transducer_loss_backward_colsum": (
         [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
          P, P, I64, P], ctypes.c_int),
+    "caiman_lstm_weight_images": ([P, I32, I32, P], ctypes.c_int),
     "caiman_proj_gemm_supported": ([P, I32], ctypes.c_int),
     "caiman_proj_gemm": ([P, I32, I32, I32, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),

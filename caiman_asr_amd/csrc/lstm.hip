@@ -2350,7 +2350,8 @@ bool try_bwd_resident2_bt(const BwdSlots<T>& w, int n_slots, int n_launches, int
 template <typename T>
 int prepare_fwd(const T* R, const T* h0, T* Rtile, T* hring, int64_t B, int64_t H, hipStream_t s) {
   if (hipMemsetAsync(hring, 0, sizeof(T) * (size_t)(2 * pad32(B) * H), s) != hipSuccess) return check_launch("lstm prepare memset");
-  hipLaunchKernelGGL((tile_R_fwd_kernel<T>), dim3((unsigned)((4 * H * H + 255) / 256)), dim3(256), 0, s, R, Rtile, (int)H);
+  if (R)   // R == nullptr: Rtile already holds the image (caiman_lstm_weight_images)
+    hipLaunchKernelGGL((tile_R_fwd_kernel<T>), dim3((unsigned)((4 * H * H + 255) / 256)), dim3(256), 0, s, R, Rtile, (int)H);
   hipLaunchKernelGGL((tile_rows_kernel<T>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, h0, hring, (int)B, (int)H);
   return check_launch("lstm prepare forward");
 }
@@ -2359,6 +2360,7 @@ template <typename T>
 int prepare_bwd(const T* R, T* Rttile, T* dring, float* dC, int64_t B, int64_t H, hipStream_t s, bool il = false) {
   if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * pad32(B) * 4 * H), s) != hipSuccess) return check_launch("lstm prepare memset");
   if (hipMemsetAsync(dC, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+  if (!R) return check_launch("lstm prepare backward");   // the image is already there (caiman_lstm_weight_images)
   if (il) hipLaunchKernelGGL((tile_Rt_bwd_kernel<T, true>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
   else hipLaunchKernelGGL((tile_Rt_bwd_kernel<T, false>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
   return check_launch("lstm prepare backward");
@@ -2583,7 +2585,7 @@ extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_
   using namespace caiman;
   CAIMAN_CHECK(B >= 1 && H >= 32 && H % 32 == 0, "lstm_prepare: H must be a positive multiple of 32 (got %lld)", (long long)H);
   CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "lstm_prepare: the wave interface is f16 / bf16 only");
-  CAIMAN_CHECK(R && weights_tiled && ring && (backward ? dC != nullptr : h0 != nullptr), "lstm_prepare: null pointer");
+  CAIMAN_CHECK(weights_tiled && ring && (backward ? dC != nullptr : h0 != nullptr), "lstm_prepare: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == CAIMAN_BF16)
     return backward ? prepare_bwd<bf16_t>((const bf16_t*)R, (bf16_t*)weights_tiled, (bf16_t*)ring, (float*)dC, B, H, s, gate_layout != 0)

@@ -34,6 +34,7 @@ EARLY_WGRAD = int(__import__("os").environ.get("CAIMAN_EARLY_WGRAD", "1")) != 0
 # projection kernel (csrc/proj_gemm.hip) instead of 2-3 library calls; shapes outside its geometry keep the library path
 PROJ = int(__import__("os").environ.get("CAIMAN_PROJ_GEMM", "1")) != 0
 PROJ_TILE = int(__import__("os").environ.get("CAIMAN_PROJ_TILE", "0"))
+IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # one launch for all operand images of the weights
 
 
 def _proj_ok(widths, dt):
@@ -151,13 +152,31 @@ class EncoderPipeFunction(torch.autograd.Function):
         Tl = [T1] * La + [T2] * Lb + [Tp] * Lp
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         tag = _lib.dtype_tag(dt)
-        Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [_perm_cast_t(Ws[l], Hl[l], dt) for l in range(L)]   # [K, 4H]
-        bias = [_perm_cast(bWs[l] + bRs[l], Hl[l], dt) for l in range(L)]
         # grouped projection kernel: wants [4H, K] (K contiguous) images of the layers that take a chunk GEMM per tick
         use_proj = _proj_ok(set(Hl) | {f * H}, dt)
-        Wn = [(_perm_cast(Ws[l], Hl[l], dt) if (use_proj and l != 0 and l != Le) else None) for l in range(L)]
         es = torch.empty((), dtype=dt).element_size()
+        bp = _pad32(B)
+        wt = [_Scratch.get(("ep_fw", l), 4 * Hl[l] * Hl[l], dt, dev) for l in range(L)]
+        # every 16-bit image of the fp32 parameters (K-major and N-major input weights, bias sum, forward and backward
+        # fragment images of the recurrent weights) in ONE launch (csrc/lstm_images.hip) instead of ~7 small kernels per layer
+        fused_img = (IMAGES and dt in (torch.float16, torch.bfloat16) and L <= 16 and
+                     all(p_.dtype == torch.float32 and p_.is_contiguous() and p_.is_cuda for p_ in params))
+        if fused_img:
+            Wp = [torch.empty((Ws[l].shape[1], 4 * Hl[l]), dtype=dt, device=dev) for l in range(L)]
+            Wn = [(torch.empty((4 * Hl[l], Ws[l].shape[1]), dtype=dt, device=dev) if (use_proj and l != 0 and l != Le) else None)
+                  for l in range(L)]
+            bias = [torch.empty(4 * Hl[l], dtype=dt, device=dev) for l in range(L)]
+            Rp = [torch.empty(4 * Hl[l] * Hl[l], dtype=dt, device=dev) for l in range(L)]   # the BACKWARD images, kept for backward
+            imgs = (_lib.LstmImages * L)(*[
+                _lib.LstmImages(Ws[l].data_ptr(), Rs[l].data_ptr(), bWs[l].data_ptr(), bRs[l].data_ptr(), Wp[l].data_ptr(),
+                                Wn[l].data_ptr() if Wn[l] is not None else None, bias[l].data_ptr(), wt[l].data_ptr(),
+                                Rp[l].data_ptr(), Hl[l], Ws[l].shape[1]) for l in range(L)])
+            _lib.check(lib.caiman_lstm_weight_images(ctypes.cast(imgs, ctypes.c_void_p), L, tag, _lib.stream()))
+        else:
+            Rp = [R.to(dt).contiguous() for R in Rs]
+            Wp = [_perm_cast_t(Ws[l], Hl[l], dt) for l in range(L)]   # [K, 4H]
+            bias = [_perm_cast(bWs[l] + bRs[l], Hl[l], dt) for l in range(L)]
+            Wn = [(_perm_cast(Ws[l], Hl[l], dt) if (use_proj and l != 0 and l != Le) else None) for l in range(L)]
         Ga = torch.empty((La, T1, B, 4 * H), dtype=dt, device=dev)
         Gb = torch.empty((Lb, T2, B, 4 * H), dtype=dt, device=dev)
         torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=Ga[0].view(T1 * B, 4 * H))
@@ -205,13 +224,11 @@ class EncoderPipeFunction(torch.autograd.Function):
         base = [0] * L   # dropout counter base of each layer: disjoint ranges
         for l in range(1, L):
             base[l] = base[l - 1] + Tl[l - 1] * B * Hl[l - 1]
-        bp = _pad32(B)
-        wt = [_Scratch.get(("ep_fw", l), 4 * Hl[l] * Hl[l], dt, dev) for l in range(L)]
         ring = [_Scratch.get(("ep_fr", l), 2 * bp * Hl[l], dt, dev) for l in range(L)]
         st = _lib.stream()
         for l in range(L):
-            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), _lib.ptr(Y[l][0]), _lib.ptr(wt[l]), _lib.ptr(ring[l]),
-                                                None, B, Hl[l], tag, 0, INTERLEAVED, st))
+            _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), _lib.ptr(Y[l][0]), _lib.ptr(wt[l]),
+                                                _lib.ptr(ring[l]), None, B, Hl[l], tag, 0, INTERLEAVED, st))
         CHb = _post_chunk(f)
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
@@ -289,7 +306,7 @@ class EncoderPipeFunction(torch.autograd.Function):
                     tm.units = 1
                     tm.nbytes = nbytes - sum((s_.nsteps - 1) * 4 * (s_.hidden or H) ** 2 * Ga.element_size() for s_ in slots)
         saved = [x, Ga, Gb, Ya, Yb, Ca, Cb, *Wp, *Rp]
-        flags = (drop_e > 0.0, bool(Lp), drop_p > 0.0)
+        flags = (drop_e > 0.0, bool(Lp), drop_p > 0.0, fused_img)
         if drop_e > 0.0:
             saved += [YMa, YMb]
         if Lp:
@@ -352,12 +369,13 @@ class EncoderPipeFunction(torch.autograd.Function):
             delta_p = torch.empty((max(Lp - 1, 1), Tp, B, Hp), dtype=dt, device=dev)
             delta += [delta_p[p] for p in range(Lp - 1)] + [as_delta(d_top_p, Tp, Hp)]
         bp = _pad32(B)
-        wt = [_Scratch.get(("ep_bw", l), 4 * Hl[l] * Hl[l], dt, dev) for l in range(L)]
+        # flags[3]: the forward pass saved the backward fragment images themselves (caiman_lstm_weight_images)
+        wt = list(Rp) if flags[3] else [_Scratch.get(("ep_bw", l), 4 * Hl[l] * Hl[l], dt, dev) for l in range(L)]
         ring = [_Scratch.get(("ep_br", l), 2 * bp * 4 * Hl[l], dt, dev) for l in range(L)]
         dC = [_Scratch.get(("ep_bc", l), B * Hl[l], torch.float32, dev) for l in range(L)]
         for l in range(L):
-            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
-                                                B, Hl[l], tag, 1, INTERLEAVED, st))
+            _lib.check(lib.caiman_lstm_prepare(None if flags[3] else _lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
+                                                _lib.ptr(dC[l]), B, Hl[l], tag, 1, INTERLEAVED, st))
         CHb = _post_chunk(f)
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH

@@ -241,6 +241,31 @@ int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots);
 int caiman_lstm_resident_profile(uint32_t* out10);
 
 /* ------------------------------------------------------------------------- *
+ * 16-bit operand images of the LSTM parameters, every layer of a stack in one launch (csrc/lstm_images.hip).  The
+ * reference casts its fp32 master weights inside each call under autocast (custom_lstm/lstm.py:51-55, 76-140); the layer
+ * pipeline wants several layouts of them per training step.  Inputs: the fp32 parameters in the reference layout (rows
+ * [gate][unit]).  Outputs (each may be NULL), `dtype` f16 / bf16:
+ *   Wt [K, 4H] K-major, columns [unit][gate];  Wn [4H, K] rows [unit][gate];  bias [4H] = b_ih + b_hh, [unit][gate];
+ *   Rf / Rb: the recurrent weights as caiman_lstm_prepare(backward = 0 / 1, gate_layout = 1) tiles them -- pass the image
+ *   as `weights_tiled` and R = NULL to caiman_lstm_prepare, which then only initialises the rings.
+ * H % 32 == 0, K % 4 == 0, 16-byte aligned parameters.
+ * ------------------------------------------------------------------------- */
+#define CAIMAN_LSTM_IMAGES_MAX_LAYERS 16
+typedef struct {
+  const float* W_ih; /* [4H, K] */
+  const float* W_hh; /* [4H, H] */
+  const float* b_ih; /* [4H] (needed when bias != NULL) */
+  const float* b_hh;
+  void* Wt;
+  void* Wn;
+  void* bias;
+  void* Rf;
+  void* Rb;
+  int32_t H, K;
+} caiman_lstm_images_t;
+int caiman_lstm_weight_images(const caiman_lstm_images_t* layers, int n_layers, int dtype, caiman_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Grouped input-projection GEMM of the layer-pipelined LSTM stacks (csrc/proj_gemm.hip) — replaces, chunk by chunk,
  *   gates = torch.addmm(bias, x, W_ih.t())          training/lib/src/rnnt_ext/custom_lstm/lstm.py:51-55
  *   dx    = dG @ W_ih  (autograd of the same call)   and the StackTime gather / scatter around the first post_rnn
