@@ -160,7 +160,8 @@ class EncoderPipeFunction(torch.autograd.Function):
         # every 16-bit image of the fp32 parameters (K-major and N-major input weights, bias sum, forward and backward
         # fragment images of the recurrent weights) in ONE launch (csrc/lstm_images.hip) instead of ~7 small kernels per layer
         fused_img = (IMAGES and dt in (torch.float16, torch.bfloat16) and L <= 16 and
-                     all(p_.dtype == torch.float32 and p_.is_contiguous() and p_.is_cuda for p_ in params))
+                     all(p_.dtype == torch.float32 and p_.is_contiguous() and p_.is_cuda for p_ in params) and
+                     all(W.shape[1] % 4 == 0 and W.data_ptr() % 16 == 0 for W in Ws) and all(R.data_ptr() % 16 == 0 for R in Rs))
         if fused_img:
             Wp = [torch.empty((Ws[l].shape[1], 4 * Hl[l]), dtype=dt, device=dev) for l in range(L)]
             Wn = [(torch.empty((4 * Hl[l], Ws[l].shape[1]), dtype=dt, device=dev) if (use_proj and l != 0 and l != Le) else None)

@@ -35,6 +35,7 @@ def _chunk(L, T=None):
     if T is not None and T <= 128:
         return CHUNK_SHORT
     return CHUNK_DEEP if L >= 4 else CHUNK
+IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # csrc/lstm_images.hip: one launch for all weight images
 INTERLEAVED = 1  # gate layout used INSIDE the pipeline: [.., H, 4] (see include/caiman_rnnt.h)
 
 
@@ -107,9 +108,25 @@ class StackFunction(torch.autograd.Function):
         # per call (R keeps its layout: the tiling kernels absorb the permutation)
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         tag = _lib.dtype_tag(dt)
-        Rp = [R.to(dt).contiguous() for R in Rs]
-        Wp = [_perm_cast_t(W, H, dt) for W in Ws]    # [K, 4H]: NN forward, NT backward (tools/lstm_gemm_layout_bench.py)
-        bias = [_perm_cast(bWs[l] + bRs[l], H, dt) for l in range(L)]
+        bp = _pad32(B)
+        wt = _Scratch.get("fw", L * 4 * H * H, dt, dev).view(L, -1)
+        # all 16-bit images of the fp32 parameters in one launch (csrc/lstm_images.hip); the backward fragment images are
+        # built here too and kept for the backward pass in place of a plain 16-bit copy of R
+        fused_img = (IMAGES and dt in (torch.float16, torch.bfloat16) and L <= 16 and
+                     all(p_.dtype == torch.float32 and p_.is_contiguous() and p_.is_cuda for p_ in params) and
+                     all(W.shape[1] % 4 == 0 and W.data_ptr() % 16 == 0 for W in Ws) and all(R.data_ptr() % 16 == 0 for R in Rs))
+        if fused_img:
+            Wp = [torch.empty((W.shape[1], 4 * H), dtype=dt, device=dev) for W in Ws]
+            bias = [torch.empty(4 * H, dtype=dt, device=dev) for _ in range(L)]
+            Rp = [torch.empty(4 * H * H, dtype=dt, device=dev) for _ in range(L)]
+            imgs = (_lib.LstmImages * L)(*[
+                _lib.LstmImages(Ws[l].data_ptr(), Rs[l].data_ptr(), bWs[l].data_ptr(), bRs[l].data_ptr(), Wp[l].data_ptr(), None,
+                                bias[l].data_ptr(), wt[l].data_ptr(), Rp[l].data_ptr(), H, Ws[l].shape[1]) for l in range(L)])
+            _lib.check(lib.caiman_lstm_weight_images(ctypes.cast(imgs, ctypes.c_void_p), L, tag, _lib.stream()))
+        else:
+            Rp = [R.to(dt).contiguous() for R in Rs]
+            Wp = [_perm_cast_t(W, H, dt) for W in Ws]    # [K, 4H]: NN forward, NT backward (tools/lstm_gemm_layout_bench.py)
+            bias = [_perm_cast(bWs[l] + bRs[l], H, dt) for l in range(L)]
         G = torch.empty((L, T, B, 4 * H), dtype=dt, device=dev)
         torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=G[0].view(T * B, 4 * H))
         Y = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
@@ -119,13 +136,11 @@ class StackFunction(torch.autograd.Function):
         drop = float(p_drop) if (training and p_drop > 0.0 and L > 1) else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop > 0.0 else 0
         YM = torch.empty((L - 1, T, B, H), dtype=dt, device=dev) if drop > 0.0 else None  # masked outputs
-        bp = _pad32(B)
-        wt = _Scratch.get("fw", L * 4 * H * H, dt, dev).view(L, -1)
         ring = _Scratch.get("fr", L * 2 * bp * H, dt, dev).view(L, -1)
         st = _lib.stream()
         for l in range(L):
-            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]), _lib.ptr(ring[l]),
-                                                None, B, H, tag, 0, INTERLEAVED, st))
+            _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]),
+                                                _lib.ptr(ring[l]), None, B, H, tag, 0, INTERLEAVED, st))
         CH = _chunk(L, T)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), False)
@@ -158,7 +173,7 @@ class StackFunction(torch.autograd.Function):
         if YM is not None:
             saved.append(YM)
         ctx.save_for_backward(*saved)
-        ctx.meta = (L, T, B, H, hard, drop, seed, x.requires_grad)
+        ctx.meta = (L, T, B, H, hard, drop, seed, x.requires_grad, fused_img)
         ctx.params = params
         y_top = Y[L - 1, 1:]
         all_h, all_c = Y[:, 1:], Cs[:, 1:]
@@ -168,7 +183,7 @@ class StackFunction(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, d_top, d_allh, _d_allc):
-        L, T, B, H, hard, drop, seed, need_dx = ctx.meta
+        L, T, B, H, hard, drop, seed, need_dx, fused_img = ctx.meta
         from caiman_asr_amd.train_utils import overlap
 
         overlap.fence_collectives()
@@ -198,7 +213,7 @@ class StackFunction(torch.autograd.Function):
             extra = d_allh.to(dt)
             d_top = d_top + extra[L - 1]
         bp = _pad32(B)
-        wt = _Scratch.get("bw", L * 4 * H * H, dt, dev).view(L, -1)
+        wt = list(Rp) if fused_img else _Scratch.get("bw", L * 4 * H * H, dt, dev).view(L, -1)   # fused: the saved images
         ring = _Scratch.get("br", L * 2 * bp * 4 * H, dt, dev).view(L, -1)
         dC = _Scratch.get("bc", L * B * H, torch.float32, dev).view(L, -1)
         # bias gradients from the backward kernels (BwdSlot.dbias) where the weight-resident kernels run; otherwise one
@@ -206,8 +221,8 @@ class StackFunction(torch.autograd.Function):
         fused_db = bool(lib.caiman_lstm_resident_would_run(B, H, min(8, L)))
         dbias = torch.zeros((L, 4 * H), dtype=torch.float32, device=dev) if fused_db else None
         for l in range(L):
-            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]), _lib.ptr(dC[l]),
-                                                B, H, tag, 1, INTERLEAVED, st))
+            _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
+                                                _lib.ptr(dC[l]), B, H, tag, 1, INTERLEAVED, st))
         CH = _chunk(L, T)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), True)
