@@ -11,7 +11,7 @@ from collections import defaultdict
 def short(name):
     m = re.search(r"(lstm_bwd_resident2_bt|lstm_fwd_resident_bt|lstm_bwd_resident2|lstm_bwd_resident|lstm_fwd_resident|lstm_bwd_step_mfma|lstm_fwd_step_mfma|"
                   r"loss_bwd_colsum_kernel|loss_row_desc_kernel|loss_bwd_kernel|loss_fwd_kernel|lse_rows_kernel|joint_bwd_kernel|"
-                  r"joint_fwd_kernel|lamb_stage1|lamb_stage2|beam_topk_kernel|lstm_cell_kernel|proj_gemm_kernel)", name)
+                  r"joint_fwd_kernel|lamb_stage1|lamb_stage2|beam_topk_kernel|lstm_cell_kernel|proj_gemm_kernel|lstm_images_kernel)", name)
     if m:
         return m.group(1)
     if name.startswith("Cijk") or name.startswith("Custom_Cijk"):
