@@ -384,3 +384,52 @@ def test_prediction_network_rides_in_the_encoder_launches(pred_layers, pred_hid,
     assert set(gr0) == set(gr1)
     for n in gr0:
         assert torch.allclose(gr0[n], gr1[n], atol=3e-2 * float(gr0[n].abs().max()) + 1e-6, rtol=0), n
+
+
+@pytest.mark.parametrize("T1, factor, dt, drop", [(75, 2, torch.bfloat16, 0.0), (70, 3, torch.bfloat16, 0.2), (33, 2, torch.float16, 0.0),
+                                                  (64, 2, torch.float16, 0.2)])
+def test_grouped_projection_and_fused_weight_images_match_the_library_path(T1, factor, dt, drop):
+    """H = 128 is the smallest width the grouped projection kernel takes (N = 512, K = 128 / factor * 128): the encoder
+    pipeline with the hand-written chunk GEMMs + one-launch weight images against the same pipeline on the library calls
+    (CAIMAN_PROJ_GEMM=0 / CAIMAN_LSTM_IMAGES=0 behaviour), ragged lengths, StackTime factor 2 and 3, both 16-bit types,
+    with and without inter-layer dropout (same seed -> same masks)."""
+    from caiman_asr_amd.rnnt.model import RNNT
+    from caiman_asr_amd.rnnt_ext.custom_lstm import encoder_pipe as ep
+    from caiman_asr_amd.rnnt_ext.custom_lstm import stack as stk
+
+    torch.manual_seed(0)
+    m = RNNT(n_classes=29, in_feats=48, enc_n_hid=128, enc_pre_rnn_layers=2, enc_post_rnn_layers=3, enc_stack_time_factor=factor,
+             enc_dropout=drop, enc_batch_norm=False, pred_n_hid=32, pred_rnn_layers=1, pred_dropout=0.0, pred_batch_norm=False,
+             joint_n_hid=48, joint_dropout=0.0, forget_gate_bias=1.0, custom_lstm=True).to(DEV).train()
+    m.encoder_pipe = True
+    B = 5
+    x = torch.randn(T1, B, 48, device=DEV)
+    lens = torch.tensor([T1, T1 - 3, T1 // 2, 7, T1], device=DEV)
+    saved = (ep.PROJ, ep.IMAGES, stk.IMAGES)
+    outs = []
+    try:
+        for proj, images in ((False, False), (True, True), (False, True)):
+            ep.PROJ, ep.IMAGES, stk.IMAGES = proj, images, images
+            m.zero_grad()
+            torch.manual_seed(123)
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=dt):
+                f, f_lens, _ = m.encode(xi, lens)
+            w = torch.linspace(0.5, 1.5, f.numel(), device=DEV).view_as(f)
+            (f.float() * w).sum().backward()
+            grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None and n.startswith("encoder")}
+            outs.append((f.detach().float(), xi.grad.clone(), grads))
+    finally:
+        ep.PROJ, ep.IMAGES, stk.IMAGES = saved
+    (f0, dx0, g0), (f1, dx1, g1), (f2, dx2, g2) = outs
+    # the one-launch weight images are bit-identical to the separately built ones: so is everything downstream
+    assert torch.equal(f0, f2) and torch.equal(dx0, dx2)
+    for n in g0:
+        assert torch.equal(g0[n], g2[n]), n
+    # the hand-written GEMM sums in another order than the library's: equal to the storage type's resolution
+    tol = 2e-2 if dt == torch.bfloat16 else 4e-3
+    assert torch.allclose(f0, f1, atol=tol * float(f0.abs().max()), rtol=0)
+    assert torch.allclose(dx0, dx1, atol=1.5 * tol * float(dx0.abs().max()), rtol=0)
+    assert len(g0) == 20
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], atol=1.5 * tol * float(g0[n].abs().max()) + 1e-6, rtol=0), n
