@@ -147,6 +147,7 @@ _SIGS = {
     "caiman_lstm_dropout_mask": ([P, I64, ctypes.c_uint64, ctypes.c_uint64, F32, I32, P], ctypes.c_int),
     "caiman_lstm_resident_mode": ([I32], ctypes.c_int),
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
+    "caiman_lstm_resident_xcd_roles": ([I32], ctypes.c_int),
     "caiman_lstm_resident_bwd_split": ([I32], ctypes.c_int),
     "caiman_lstm_resident_profile_bwd2": ([P], ctypes.c_int),
     "caiman_lstm_resident_set_failures": ([I32], ctypes.c_int),
@@ -218,6 +219,8 @@ def lib():
         _lib = L
         if os.environ.get("CAIMAN_LSTM_RESIDENT", "") in ("0", "1", "2"):   # weight-resident LSTM chunk kernels (csrc/lstm.hip)
             L.caiman_lstm_resident_mode(int(os.environ["CAIMAN_LSTM_RESIDENT"]))
+        if os.environ.get("CAIMAN_LSTM_XCD_ROLES", "") in ("0", "1"):       # layer -> XCD placement of the resident launches (A/B runs)
+            L.caiman_lstm_resident_xcd_roles(int(os.environ["CAIMAN_LSTM_XCD_ROLES"]))
         if os.environ.get("CAIMAN_LSTM_BWD_SPLIT", "") in ("0", "1"):       # 2-D split backward resident kernel (A/B runs)
             L.caiman_lstm_resident_bwd_split(int(os.environ["CAIMAN_LSTM_BWD_SPLIT"]))
     return _lib

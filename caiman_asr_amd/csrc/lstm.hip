@@ -560,6 +560,24 @@ constexpr size_t kResSyncBytesBT = (size_t)(kMaxSlots * kResMaxTiles * 12 + 1) *
 // block that the launch HALF A POOL LATER will use.  Resident launches are totally ordered (res_begin), so that block
 // belongs to no launch in flight: its last user finished half a pool ago and its next user starts after this launch
 // has completed (the kernel-end release makes the stores visible to it).
+// Workgroup -> (slot, position in the slot).  Default: grid (NKS, slots).  XCD-local roles: a flat grid of 8 * NKS
+// workgroups, slot = block % 8: blocks are dealt round-robin over the 8 XCDs (observed, not promised -- and nothing here
+// depends on it for correctness: the hand-off protocol is placement-independent), so the NKS workgroups of a slot share
+// one XCD and its L2: tools/handoff_xcd_microbench.hip measures 2.29 instead of 2.66 us per 64 KB hand-off (1.96 with plain
+// instead of sc1 stores, which is only valid when the co-location holds).  In the real kernels the placement alone gains
+// nothing (forward 4.70 vs 4.78, backward 6.85 vs 6.77 us per timestep; training step 28.0-28.3 vs 27.9 ms: the sc1 stores
+// drop the line from the XCD's L2 either way), so it is OFF by default.  Slots past the launch's count have nsteps = 0
+// and leave at once.
+template <int NKS>
+__device__ __forceinline__ void res_role(int& slot, int& j) {
+  if (gridDim.y == 1 && gridDim.x == (unsigned)(NKS * 8)) {
+    slot = (int)(blockIdx.x & 7u);
+    j = (int)(blockIdx.x >> 3);
+  } else {
+    slot = (int)blockIdx.y;
+    j = (int)blockIdx.x;
+  }
+}
 __device__ inline void res_scrub(unsigned* blk, int words) {
   if (blockIdx.x == 0 && blockIdx.y == 0)
     for (int i = threadIdx.x; i < words; i += blockDim.x)
@@ -624,11 +642,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
   T* tr = hs + 32 * LDH;                                    // [4 waves][2: h, c][32 rows][8 units]
   int* flag = reinterpret_cast<int*>(tr + 4 * 2 * 32 * 8);  // abort broadcast
 
-  const int slot = blockIdx.y, j = blockIdx.x;
+  int slot, j;
+  res_role<NKS>(slot, j);
   const int nsteps = w.nsteps[slot];
   res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
   if (nsteps <= 0) return;
-  const int nwg = gridDim.x;
+  const int nwg = NKS;
   unsigned* cnt = sync + slot * kResCounterStride;
   unsigned* fail_dev = sync + kMaxSlots * kResCounterStride;
   const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
@@ -854,11 +873,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, in
   T* tr = hs + 32 * LDH;                                    // [4 waves][2: h, c][32 rows][8 units]
   int* flag = reinterpret_cast<int*>(tr + 4 * 2 * 32 * 8);  // abort broadcast
 
-  const int slot = blockIdx.y, j = blockIdx.x;
+  int slot, j;
+  res_role<NKS>(slot, j);
   const int nsteps = w.nsteps[slot];
   res_scrub(scrub, (int)(kResSyncBytesBT / sizeof(unsigned)));
   if (nsteps <= 0) return;
-  const int nwg = gridDim.x;
+  const int nwg = NKS;
   const int ntiles = (B + 31) / 32;
   unsigned* fail_dev = sync + kMaxSlots * kResMaxTiles * 12 * kResCounterStride;
   auto counter = [&](int bt) -> unsigned* { return sync + ((slot * kResMaxTiles + bt) * 12) * kResCounterStride; };
@@ -1106,11 +1126,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   float* red = reinterpret_cast<float*>(buf + (DMA ? 0 : NB * 32 * LDW));   // [kh 2][rt 2][ct 2][16 units][17]
   int* flag = reinterpret_cast<int*>(red + 8 * 16 * 17);
 
-  const int slot = blockIdx.y, j = blockIdx.x;
+  int slot, j;
+  res_role<NKS>(slot, j);
   const int nsteps = w.nsteps[slot];
   res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
   if (nsteps <= 0) return;
-  const int nwg = gridDim.x;
+  const int nwg = NKS;
   unsigned* cnt = sync + slot * kResCounterStride;
   unsigned* fail_dev = sync + kMaxSlots * kResCounterStride;
   const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
@@ -1413,7 +1434,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
   int* flag = reinterpret_cast<int*>(ownp + 32 * 36);
   auto ring = [&](int k) -> T* { return k == 0 ? ring0 : ring1; };
 
-  const int slot = blockIdx.y, bx = blockIdx.x;
+  int slot, bx;
+  res_role<NKS>(slot, bx);
   const int nsteps = w.nsteps[slot];
   res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
   if (nsteps <= 0) return;
@@ -1701,7 +1723,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
   int* flag = reinterpret_cast<int*>(ownp + 32 * 36);
   auto ring = [&](int k) -> T* { return k == 0 ? ring0 : ring1; };
 
-  const int slot = blockIdx.y, bx = blockIdx.x;
+  int slot, bx;
+  res_role<NKS>(slot, bx);
   const int nsteps = w.nsteps[slot];
   res_scrub(scrub, (int)(kResSyncBytesBT / sizeof(unsigned)));
   if (nsteps <= 0) return;
@@ -2071,6 +2094,11 @@ struct ResState {
 std::mutex g_res_mu;
 ResState g_res[16];
 std::atomic<int> g_res_mode{1};
+std::atomic<int> g_res_xcd_roles{0};   // flat grid with slot = block % 8 (res_role): a slot's workgroups share an XCD (measured: no gain)
+inline dim3 res_grid(int nks, int n_slots, int cus) {
+  if (g_res_xcd_roles.load(std::memory_order_relaxed) && nks * 8 <= cus) return dim3((unsigned)(nks * 8));
+  return dim3((unsigned)nks, (unsigned)n_slots);
+}
 std::atomic<int> g_res_bwd_split{1};   // 2-D split backward kernel where the shape allows it (H = 512, 1024)
 std::atomic<long long> g_res_launches{0};
 
@@ -2135,7 +2163,7 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
   unsigned* scrub = nullptr;
   unsigned* sync = res_begin(st, s, &scrub);
-  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const dim3 grid = res_grid(nks, n_slots, st->cus);
   const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
   do {                                                                                                               \
@@ -2194,7 +2222,7 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
   unsigned* scrub = nullptr;
   unsigned* sync = res_begin(st, s, &scrub);
-  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const dim3 grid = res_grid(nks, n_slots, st->cus);
   const size_t lds = res_bwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
   do {                                                                                                               \
@@ -2246,7 +2274,7 @@ bool try_bwd_resident2(const BwdSlots<T>& w, int n_slots, int n_launches, int64_
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
   unsigned* scrub = nullptr;
   unsigned* sync = res_begin(st, s, &scrub);
-  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const dim3 grid = res_grid(nks, n_slots, st->cus);
   const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
   const bool prof = g_res_mode.load(std::memory_order_relaxed) == 2;
 #define CAIMAN_RES2(NKV)                                                                                             \
@@ -2296,7 +2324,7 @@ bool try_fwd_resident_bt(const FwdSlots<T>& w, int n_slots, int n_launches, int6
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
   unsigned* scrub = nullptr;
   unsigned* sync = res_begin_bt(st, s, &scrub);
-  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const dim3 grid = res_grid(nks, n_slots, st->cus);
   const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RESBT(NKV)                                                                                            \
   do {                                                                                                               \
@@ -2336,7 +2364,7 @@ bool try_bwd_resident2_bt(const BwdSlots<T>& w, int n_slots, int n_launches, int
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
   unsigned* scrub = nullptr;
   unsigned* sync = res_begin_bt(st, s, &scrub);
-  const dim3 grid((unsigned)nks, (unsigned)n_slots);
+  const dim3 grid = res_grid(nks, n_slots, st->cus);
   const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
   if (nks == 16)
     hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
@@ -2492,6 +2520,10 @@ extern "C" int caiman_lstm_resident_mode(int mode) {
 // 1 (default): backward wave calls with H = 512 / 1024 use the 2-D split resident kernel (a workgroup gathers a
 // quarter of the dG row, the four K-quarter partials meet in a second hand-off); 0: the round-1 kernel (whole row per
 // workgroup).  Returns the previous setting.  For A/B measurements and tests.
+// Resident launches as a flat grid whose workgroup -> slot mapping puts a slot on one XCD (1) or as grid (NKS, slots) (0, default).
+// Placement only changes the speed.  Returns the previous setting.
+extern "C" int caiman_lstm_resident_xcd_roles(int on) { return caiman::g_res_xcd_roles.exchange(on ? 1 : 0); }
+
 extern "C" int caiman_lstm_resident_bwd_split(int on) { return caiman::g_res_bwd_split.exchange(on ? 1 : 0); }
 
 // Mode 2 phase timers of the 2-D split backward kernel (workgroup 0 of slot 0), 10 ns ticks summed over timesteps:

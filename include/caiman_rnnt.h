@@ -239,6 +239,11 @@ int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots);
  * including the staged MFMAs), in the MFMA + cell update (backward: the epilogue), draining the stores + barrier},
  * summed over timesteps, then the timestep count.  Synchronises the device and clears the counters. */
 int caiman_lstm_resident_profile(uint32_t* out10);
+/* 1: resident launches are a flat grid whose workgroup -> layer mapping follows the dispatcher's round-robin over the
+ * XCDs, so that the workgroups of a layer share one XCD's L2; 0 (default; measured equal or better): grid (H / 32, layers).
+ * Placement only changes the speed
+ * (the hand-off protocol does not depend on it).  Returns the previous setting. */
+int caiman_lstm_resident_xcd_roles(int on);
 
 /* ------------------------------------------------------------------------- *
  * 16-bit operand images of the LSTM parameters, every layer of a stack in one launch (csrc/lstm_images.hip).  The
