@@ -105,6 +105,12 @@ class LstmImages(ctypes.Structure):
                 ("Rb", ctypes.c_void_p), ("H", ctypes.c_int32), ("K", ctypes.c_int32)]
 
 
+class GradItem(ctypes.Structure):
+    """caiman_lstm_grad_item_t (include/caiman_rnnt.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("H", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("src_fp32", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class BeamConfig(ctypes.Structure):
     """caiman_beam_config_t (include/caiman_beam.h)."""
     _fields_ = [("blank_idx", ctypes.c_int32), ("beam_width", ctypes.c_int32),
@@ -137,6 +143,7 @@ _SIGS = {
         [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, F64, I64, F64, I64, F64, I64, I32, I32,
          P, P, I64, P], ctypes.c_int),
     "caiman_lstm_weight_images": ([P, I32, I32, P], ctypes.c_int),
+    "caiman_lstm_grad_deliver": ([P, I32, I32, P], ctypes.c_int),
     "caiman_proj_gemm_supported": ([P, I32], ctypes.c_int),
     "caiman_proj_gemm": ([P, I32, I32, I32, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),

@@ -92,8 +92,73 @@ __global__ __launch_bounds__(256) void lstm_images_kernel(ImgBatch ib) {
   }
 }
 
+// The way back: a layer's parameter gradients leave the pipeline with rows in [unit][gate] order (16-bit GEMM outputs
+// for the weights, fp32 row sums for the biases) and are ADDED into the fp32 `.grad` views of the optimiser's arena in the
+// reference layout (rows [gate][unit]): un-permute + widen + accumulate for the four parameters of a layer in one launch
+// (was one torch kernel per parameter: 50 launches, 0.35 ms per step).
+constexpr int kDeliverMax = CAIMAN_LSTM_DELIVER_MAX_ITEMS;
+struct DeliverBatch {
+  caiman_lstm_grad_item_t it[kDeliverMax];
+  int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_grad_deliver_kernel(DeliverBatch db) {
+  const caiman_lstm_grad_item_t& I = db.it[blockIdx.y];
+  const int H = I.H, cols = I.cols;
+  float* __restrict__ dst = I.dst;
+  if (cols % 4 == 0) {
+    const int c4n = cols / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)4 * H * c4n) return;
+    const int r = (int)(i / c4n), c = (int)(i - (int64_t)r * c4n) * 4;     // r = unit * 4 + gate
+    const int64_t d = (int64_t)((r & 3) * H + (r >> 2)) * cols + c;
+    float4 a = *reinterpret_cast<const float4*>(dst + d);
+    if (I.src_fp32) {
+      const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(I.src) + (int64_t)r * cols + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    } else {
+      using v4 = __attribute__((ext_vector_type(4))) T;
+      const v4 v = *reinterpret_cast<const v4*>(static_cast<const T*>(I.src) + (int64_t)r * cols + c);
+      a.x += static_cast<float>(v[0]); a.y += static_cast<float>(v[1]); a.z += static_cast<float>(v[2]); a.w += static_cast<float>(v[3]);
+    }
+    *reinterpret_cast<float4*>(dst + d) = a;
+  } else {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)4 * H * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    const int64_t d = (int64_t)((r & 3) * H + (r >> 2)) * cols + c;
+    dst[d] += I.src_fp32 ? static_cast<const float*>(I.src)[i] : static_cast<float>(static_cast<const T*>(I.src)[i]);
+  }
+}
+
 }  // namespace
 }  // namespace caiman
+
+extern "C" int caiman_lstm_grad_deliver(const caiman_lstm_grad_item_t* items, int n_items, int dtype, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(items && n_items >= 1 && n_items <= kDeliverMax, "caiman_lstm_grad_deliver: 1 .. %d items per call", kDeliverMax);
+  CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "caiman_lstm_grad_deliver: 16-bit sources are f16 / bf16");
+  DeliverBatch db;
+  db.n = n_items;
+  int64_t most = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const caiman_lstm_grad_item_t& I = items[i];
+    CAIMAN_CHECK(I.src && I.dst && I.H >= 1 && I.cols >= 1, "caiman_lstm_grad_deliver: item %d: null pointer or empty extent", i);
+    CAIMAN_CHECK(I.cols % 4 != 0 || (((reinterpret_cast<uintptr_t>(I.dst) & 15u) == 0) &&
+                                     ((reinterpret_cast<uintptr_t>(I.src) & (I.src_fp32 ? 15u : 7u)) == 0)),
+                 "caiman_lstm_grad_deliver: item %d: misaligned pointer", i);
+    db.it[i] = I;
+    const int64_t work = I.cols % 4 == 0 ? (int64_t)4 * I.H * (I.cols / 4) : (int64_t)4 * I.H * I.cols;
+    most = work > most ? work : most;
+  }
+  for (int i = n_items; i < kDeliverMax; ++i) db.it[i] = items[0];
+  const dim3 grid((unsigned)((most + 255) / 256), (unsigned)n_items);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == CAIMAN_BF16) hipLaunchKernelGGL((lstm_grad_deliver_kernel<bf16_t>), grid, dim3(256), 0, s, db);
+  else hipLaunchKernelGGL((lstm_grad_deliver_kernel<f16_t>), grid, dim3(256), 0, s, db);
+  return check_launch("lstm gradient delivery");
+}
 
 extern "C" int caiman_lstm_weight_images(const caiman_lstm_images_t* layers, int n_layers, int dtype, caiman_stream_t stream) {
   using namespace caiman;

@@ -526,8 +526,22 @@ class EncoderPipeFunction(torch.autograd.Function):
                 dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)
                 g4 = [torch.matmul(dg.t(), layer_input(l)), torch.matmul(dg.t(), yprev), dB, dB]
             if direct:
-                for p_, g_ in zip(ctx.params[4 * l:4 * l + 4], g4):
-                    deliver(p_, g_, hl)
+                ps = ctx.params[4 * l:4 * l + 4]
+                if (IMAGES and all(p_.requires_grad and p_.dtype == torch.float32 and p_.is_contiguous() for p_ in ps)
+                        and all(g_.is_contiguous() and g_.dtype in (dt, torch.float32) for g_ in g4)):
+                    # the four parameters of the layer in one launch (un-permute + widen + accumulate)
+                    for p_ in ps:
+                        if p_.grad is None:
+                            p_.grad = torch.zeros_like(p_)
+                    items = (_lib.GradItem * 4)(*[
+                        _lib.GradItem(g_.data_ptr(), p_.grad.data_ptr(), hl, p_.shape[1] if p_.dim() == 2 else 1,
+                                      int(g_.dtype == torch.float32), 0) for p_, g_ in zip(ps, g4)])
+                    _lib.check(lib.caiman_lstm_grad_deliver(ctypes.cast(items, ctypes.c_void_p), 4, tag, st))
+                    for p_ in ps:
+                        overlap.notify_grad_ready(p_)
+                else:
+                    for p_, g_ in zip(ps, g4):
+                        deliver(p_, g_, hl)
                 g4 = [None] * 4
             else:
                 g4 = [_unperm_rows(g_, hl) for g_ in g4]

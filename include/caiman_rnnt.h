@@ -269,6 +269,19 @@ typedef struct {
   int32_t H, K;
 } caiman_lstm_images_t;
 int caiman_lstm_weight_images(const caiman_lstm_images_t* layers, int n_layers, int dtype, caiman_stream_t stream);
+/* The way back for the gradients: dst[(gate * H + unit) * cols + c] += src[(unit * 4 + gate) * cols + c] for up to 8
+ * parameters in one launch.  dst: the fp32 `.grad` of a parameter in the reference layout (rows [gate][unit]); src: the
+ * gradient as the layer pipeline produces it (rows [unit][gate]), `dtype` (f16 / bf16) or fp32 when src_fp32 != 0 (the bias
+ * sums of the backward kernels); cols = K for a weight, 1 for a bias.  Replaces autograd's AccumulateGrad of
+ * `dW, dR, dB, dB` (custom_lstm/lstm.py:119-144) plus this repo's un-permutation. */
+#define CAIMAN_LSTM_DELIVER_MAX_ITEMS 8
+typedef struct {
+  const void* src;
+  float* dst;
+  int32_t H, cols;
+  int32_t src_fp32, reserved;
+} caiman_lstm_grad_item_t;
+int caiman_lstm_grad_deliver(const caiman_lstm_grad_item_t* items, int n_items, int dtype, caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Grouped input-projection GEMM of the layer-pipelined LSTM stacks (csrc/proj_gemm.hip) — replaces, chunk by chunk,

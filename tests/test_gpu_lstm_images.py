@@ -65,3 +65,27 @@ def test_bad_geometry_is_refused():
     with pytest.raises(RuntimeError):
         _lib.check(_lib.lib().caiman_lstm_weight_images(ctypes.cast(arr, ctypes.c_void_p), 1, _lib.dtype_tag(torch.bfloat16),
                                                          _lib.stream()))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,K", [(32, 240), (64, 36), (512, 1024), (96, 7)])
+def test_grad_deliver_adds_the_unpermuted_gradients(H, K, dt):
+    """caiman_lstm_grad_deliver: dst[(gate*H + unit)*cols + c] += src[(unit*4 + gate)*cols + c] for the four parameters of a
+    layer in one launch, 16-bit weight gradients and fp32 bias sums -- against the torch expression it replaces."""
+    from caiman_asr_amd import _lib
+
+    g = torch.Generator().manual_seed(H + K)
+    gW = torch.randn(4 * H, K, generator=g).to(dt).to(DEV)
+    gR = torch.randn(4 * H, H, generator=g).to(dt).to(DEV)
+    gB = torch.randn(4 * H, generator=g).to(DEV)
+    dst = [torch.randn(4 * H, K, generator=g).to(DEV), torch.randn(4 * H, H, generator=g).to(DEV),
+           torch.randn(4 * H, generator=g).to(DEV), torch.randn(4 * H, generator=g).to(DEV)]
+    ref = [d.clone() for d in dst]
+    for r, s in zip(ref, (gW, gR, gB, gB)):
+        r.view(4, H, *r.shape[1:]).add_(s.view(H, 4, *s.shape[1:]).transpose(0, 1))
+    items = (_lib.GradItem * 4)(*[_lib.GradItem(s.data_ptr(), d.data_ptr(), H, d.shape[1] if d.dim() == 2 else 1,
+                                                int(s.dtype == torch.float32), 0) for d, s in zip(dst, (gW, gR, gB, gB))])
+    _lib.check(_lib.lib().caiman_lstm_grad_deliver(ctypes.cast(items, ctypes.c_void_p), 4, _lib.dtype_tag(dt), _lib.stream()))
+    torch.cuda.synchronize()
+    for d, r in zip(dst, ref):
+        assert torch.equal(d, r)
