@@ -161,3 +161,28 @@ def test_split_and_whole_row_backward_kernels_agree_and_are_deterministic(H):
     for i, (x1, x2) in enumerate(zip(a1, b)):
         scale = float(x2.abs().max()) + 1e-6
         assert torch.allclose(x1.float(), x2.float(), atol=(8e-3 if i < 4 else 2e-2) * scale, rtol=0), i
+
+
+@pytest.mark.parametrize("T,B,H", [(21, 32, 1024), (9, 64, 512)])
+def test_layer_to_xcd_placement_option_does_not_change_the_results(T, B, H):
+    """caiman_lstm_resident_xcd_roles(1) launches the resident kernels as a flat grid whose workgroup -> layer mapping puts
+    a layer on one XCD; the hand-off protocol is placement-independent and the arithmetic identical: bit-equal outputs."""
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(T * H)
+    dt = torch.bfloat16
+    R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dt)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    y0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    delta = torch.randn(T, B, H, generator=g).to(dt)
+    prev = lib.caiman_lstm_resident_xcd_roles(0)
+    try:
+        a = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+        lib.caiman_lstm_resident_xcd_roles(1)
+        b = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+    finally:
+        lib.caiman_lstm_resident_xcd_roles(prev)
+    for x1, x2 in zip(a, b):
+        assert torch.equal(x1, x2)
