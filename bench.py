@@ -474,7 +474,7 @@ def main():
                                    "chain": {"us_per_timestep": us_ts, "mfma_floor_us_per_timestep": 0.85,
                                              "frac_of_floor": 0.85 / us_ts},
                                    "note": ("live HIP-event measurement; avg_launch_us is event-to-event over sampled brackets "
-                                            "(kernel + its counter memset + the events' own cost).  `bound` names the roofline the "
+                                            "(kernel + the events' own cost).  `bound` names the roofline the "
                                             "algorithmic bytes are priced against; the kernel itself is bounded by its chain of "
                                             "dependent timesteps (hand-off of the dG row between the workgroups of a layer): "
                                             "`chain`, DESIGN.md section 4")}
