@@ -2376,8 +2376,8 @@ bool try_bwd_resident2_bt(const BwdSlots<T>& w, int n_slots, int n_launches, int
 }
 
 template <typename T>
-int prepare_fwd(const T* R, const T* h0, T* Rtile, T* hring, int64_t B, int64_t H, hipStream_t s) {
-  if (hipMemsetAsync(hring, 0, sizeof(T) * (size_t)(2 * pad32(B) * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+int prepare_fwd(const T* R, const T* h0, T* Rtile, T* hring, int64_t B, int64_t H, hipStream_t s, bool zeroed = false) {
+  if (!zeroed && hipMemsetAsync(hring, 0, sizeof(T) * (size_t)(2 * pad32(B) * H), s) != hipSuccess) return check_launch("lstm prepare memset");
   if (R)   // R == nullptr: Rtile already holds the image (caiman_lstm_weight_images)
     hipLaunchKernelGGL((tile_R_fwd_kernel<T>), dim3((unsigned)((4 * H * H + 255) / 256)), dim3(256), 0, s, R, Rtile, (int)H);
   hipLaunchKernelGGL((tile_rows_kernel<T>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, h0, hring, (int)B, (int)H);
@@ -2385,9 +2385,11 @@ int prepare_fwd(const T* R, const T* h0, T* Rtile, T* hring, int64_t B, int64_t 
 }
 
 template <typename T>
-int prepare_bwd(const T* R, T* Rttile, T* dring, float* dC, int64_t B, int64_t H, hipStream_t s, bool il = false) {
-  if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * pad32(B) * 4 * H), s) != hipSuccess) return check_launch("lstm prepare memset");
-  if (hipMemsetAsync(dC, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+int prepare_bwd(const T* R, T* Rttile, T* dring, float* dC, int64_t B, int64_t H, hipStream_t s, bool il = false, bool zeroed = false) {
+  if (!zeroed) {
+    if (hipMemsetAsync(dring, 0, sizeof(T) * (size_t)(2 * pad32(B) * 4 * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+    if (hipMemsetAsync(dC, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return check_launch("lstm prepare memset");
+  }
   if (!R) return check_launch("lstm prepare backward");   // the image is already there (caiman_lstm_weight_images)
   if (il) hipLaunchKernelGGL((tile_Rt_bwd_kernel<T, true>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
   else hipLaunchKernelGGL((tile_Rt_bwd_kernel<T, false>), dim3((unsigned)((H / 16) * (4 * H / 32))), dim3(256), 0, s, R, Rttile, (int)H);
@@ -2619,11 +2621,12 @@ extern "C" int caiman_lstm_prepare(const void* R, const void* h0, void* weights_
   CAIMAN_CHECK(dtype == CAIMAN_F16 || dtype == CAIMAN_BF16, "lstm_prepare: the wave interface is f16 / bf16 only");
   CAIMAN_CHECK(weights_tiled && ring && (backward ? dC != nullptr : h0 != nullptr), "lstm_prepare: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool il = (gate_layout & 1) != 0, zeroed = (gate_layout & 2) != 0;   // bit 1: the caller has already zeroed ring (and dC)
   if (dtype == CAIMAN_BF16)
-    return backward ? prepare_bwd<bf16_t>((const bf16_t*)R, (bf16_t*)weights_tiled, (bf16_t*)ring, (float*)dC, B, H, s, gate_layout != 0)
-                    : prepare_fwd<bf16_t>((const bf16_t*)R, (const bf16_t*)h0, (bf16_t*)weights_tiled, (bf16_t*)ring, B, H, s);
-  return backward ? prepare_bwd<f16_t>((const f16_t*)R, (f16_t*)weights_tiled, (f16_t*)ring, (float*)dC, B, H, s, gate_layout != 0)
-                  : prepare_fwd<f16_t>((const f16_t*)R, (const f16_t*)h0, (f16_t*)weights_tiled, (f16_t*)ring, B, H, s);
+    return backward ? prepare_bwd<bf16_t>((const bf16_t*)R, (bf16_t*)weights_tiled, (bf16_t*)ring, (float*)dC, B, H, s, il, zeroed)
+                    : prepare_fwd<bf16_t>((const bf16_t*)R, (const bf16_t*)h0, (bf16_t*)weights_tiled, (bf16_t*)ring, B, H, s, zeroed);
+  return backward ? prepare_bwd<f16_t>((const f16_t*)R, (f16_t*)weights_tiled, (f16_t*)ring, (float*)dC, B, H, s, il, zeroed)
+                  : prepare_fwd<f16_t>((const f16_t*)R, (const f16_t*)h0, (f16_t*)weights_tiled, (f16_t*)ring, B, H, s, zeroed);
 }
 
 extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_slots, int n_launches, int64_t B,

@@ -225,11 +225,17 @@ class EncoderPipeFunction(torch.autograd.Function):
         base = [0] * L   # dropout counter base of each layer: disjoint ranges
         for l in range(1, L):
             base[l] = base[l - 1] + Tl[l - 1] * B * Hl[l - 1]
-        ring = [_Scratch.get(("ep_fr", l), 2 * bp * Hl[l], dt, dev) for l in range(L)]
+        # the h rings of all layers: one buffer, one memset (caiman_lstm_prepare then only tiles the initial state in)
+        ring_all = _Scratch.get(("ep_fr_all",), sum(2 * bp * h for h in Hl), dt, dev)
+        ring_all.zero_()
+        ring, off = [], 0
+        for h in Hl:
+            ring.append(ring_all[off:off + 2 * bp * h])
+            off += 2 * bp * h
         st = _lib.stream()
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), _lib.ptr(Y[l][0]), _lib.ptr(wt[l]),
-                                                _lib.ptr(ring[l]), None, B, Hl[l], tag, 0, INTERLEAVED, st))
+                                                _lib.ptr(ring[l]), None, B, Hl[l], tag, 0, INTERLEAVED | 2, st))
         CHb = _post_chunk(f)
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
@@ -372,11 +378,22 @@ class EncoderPipeFunction(torch.autograd.Function):
         bp = _pad32(B)
         # flags[3]: the forward pass saved the backward fragment images themselves (caiman_lstm_weight_images)
         wt = list(Rp) if flags[3] else [_Scratch.get(("ep_bw", l), 4 * Hl[l] * Hl[l], dt, dev) for l in range(L)]
-        ring = [_Scratch.get(("ep_br", l), 2 * bp * 4 * Hl[l], dt, dev) for l in range(L)]
-        dC = [_Scratch.get(("ep_bc", l), B * Hl[l], torch.float32, dev) for l in range(L)]
+        # dG rings (16-bit) and dC carries (fp32) of all layers in one byte buffer: one memset instead of two per layer
+        es_ = Ga.element_size()
+        ring_b = [2 * bp * 4 * h * es_ for h in Hl]
+        dc_b = [B * h * 4 for h in Hl]
+        zero_all = _Scratch.get(("ep_bz_all",), sum(ring_b) + sum(dc_b) + 16 * L, torch.uint8, dev)
+        zero_all.zero_()
+        ring, dC, off = [], [], 0
+        for l in range(L):
+            ring.append(zero_all[off:off + ring_b[l]].view(dt))
+            off += (ring_b[l] + 15) // 16 * 16
+        for l in range(L):
+            dC.append(zero_all[off:off + dc_b[l]].view(torch.float32))
+            off += (dc_b[l] + 15) // 16 * 16
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(None if flags[3] else _lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
-                                                _lib.ptr(dC[l]), B, Hl[l], tag, 1, INTERLEAVED, st))
+                                                _lib.ptr(dC[l]), B, Hl[l], tag, 1, INTERLEAVED | 2, st))
         CHb = _post_chunk(f)
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH

@@ -191,7 +191,9 @@ typedef struct {
 /* gate_layout: 0 = the reference's gates / dG layout [B, 4, H] (gate-major, lstm.cu:99-102);
  *              1 = interleaved [B, H, 4] (the 4 gates of a hidden unit adjacent): an internal layout of the
  *                  stack pipeline (the caller permutes the rows of W_ih / biases accordingly) that turns the
- *                  epilogue's 2-byte strided accesses into 8-byte vectors. */
+ *                  epilogue's 2-byte strided accesses into 8-byte vectors.
+ * caiman_lstm_prepare only: + 2 = `ring` (and `dC`) are already zero -- the caller cleared the rings of all layers with one
+ *                  memset -- so the call issues no memset of its own. */
 int caiman_lstm_prepare(const void* R, const void* h0, void* weights_tiled, void* ring, void* dC,
                         int64_t B, int64_t H, int dtype, int backward, int gate_layout,
                         caiman_stream_t stream);
