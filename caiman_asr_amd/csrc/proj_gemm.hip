@@ -47,17 +47,28 @@ struct ProjBatch {
   int n;
 };
 
-template <typename T, int BM, int BN, int NS, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void proj_gemm_kernel(ProjBatch pb) {
+// KS = 2: two groups of NW waves share the tile and split its K range in halves (the K loop of a workgroup is a serial
+// chain of ~1 us steps; for the backward problems, K = 4H with one tile per CU, the chain IS the launch time); the halves
+// meet in LDS -- group 1 parks its accumulators in its own stage buffers, group 0 adds them and runs the epilogue.
+template <typename T, int BM, int BN, int NS, int NW, int KS>
+__global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb) {
   using frag = typename pfrag<T>::type;
   constexpr int BK = 64;
   constexpr int WGM = NW / 2;                     // waves along M; two along N
   constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int ABLK = BM / 8 / NW, WBLK = BN / 8 / NW;   // 8-row blocks (1 KB, one DMA instruction) per wave and operand
-  __shared__ __attribute__((aligned(1024))) T lA0[BM * BK], lA1[BM * BK], lW0[BN * BK], lW1[BN * BK];
+  static_assert(KS == 1 || (KS == 2 && NS == 2 && BM == 128 && BN == 128 && NW == 8), "K split: 128 x 128 tiles, two stages");
+  __shared__ __attribute__((aligned(1024))) T gA0[BM * BK], gA1[BM * BK], gW0[BN * BK], gW1[BN * BK];
   __shared__ __attribute__((aligned(1024))) T lA2[NS == 3 ? BM * BK : 8], lW2[NS == 3 ? BN * BK : 8];   // third stage
+  __shared__ __attribute__((aligned(1024))) T hA0[KS == 2 ? BM * BK : 8], hA1[KS == 2 ? BM * BK : 8], hW0[KS == 2 ? BN * BK : 8],
+      hW1[KS == 2 ? BN * BK : 8];                                                                        // second K group
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int grp = KS == 2 ? (tid >> 6) / NW : 0, wave = (tid >> 6) % NW;
+  T* const lA0 = grp ? hA0 : gA0;
+  T* const lA1 = grp ? hA1 : gA1;
+  T* const lW0 = grp ? hW0 : gW0;
+  T* const lW1 = grp ? hW1 : gW1;
   const int bid = blockIdx.x;
   int g = 0;
 #pragma unroll
@@ -137,8 +148,38 @@ __global__ __launch_bounds__(64 * NW, 1) void proj_gemm_kernel(ProjBatch pb) {
     }
   };
 
-  const int nk = K / BK;
-  if constexpr (NS == 2) {
+  const int nk = K / BK / KS;
+  const int kbeg = grp * (K / KS);
+  if constexpr (NS == 2 && KS == 2) {
+    issue(lA0, lW0, kbeg);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {   // K % 256 == 0: an even number of steps per group
+      issue(lA1, lW1, kbeg + (ks + 1) * BK);
+      compute(lA0, lW0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      if (ks + 2 < nk) issue(lA0, lW0, kbeg + (ks + 2) * BK);
+      compute(lA1, lW1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+    // the two K halves meet: 64 accumulator tiles of 1 KB (8 waves x 8 tiles) fit group 1's four 16 KB stage buffers
+    T* const park = (wave >> 1) == 0 ? hA0 : ((wave >> 1) == 1 ? hA1 : ((wave >> 1) == 2 ? hW0 : hW1));
+    f32x4* const slot = reinterpret_cast<f32x4*>(park) + ((wave & 1) * (TN * TM)) * 64 + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) slot[(a * TM + b) * 64] = acc[a][b];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] += slot[(a * TM + b) * 64];
+  } else if constexpr (NS == 2) {
     issue(lA0, lW0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMAs have landed
     __syncthreads();
@@ -224,7 +265,7 @@ __global__ __launch_bounds__(64 * NW, 1) void proj_gemm_kernel(ProjBatch pb) {
   }
 }
 
-template <typename T, int BM, int BN, int NS, int NW>
+template <typename T, int BM, int BN, int NS, int NW, int KS = 1>
 int launch_proj(const caiman_proj_problem_t* problems, int n, hipStream_t s) {
   ProjBatch pb;
   pb.n = n;
@@ -238,7 +279,7 @@ int launch_proj(const caiman_proj_problem_t* problems, int n, hipStream_t s) {
   for (int i = n; i <= kProjMax; ++i) pb.tile_begin[i] = tiles;
   for (int i = n; i < kProjMax; ++i) { pb.p[i] = problems[0]; pb.tiles_n[i] = 1; }
   if (tiles == 0) return CAIMAN_OK;
-  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, NS, NW>), dim3((unsigned)tiles), dim3(64 * NW), 0, s, pb);
+  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, NS, NW, KS>), dim3((unsigned)tiles), dim3(64 * NW * KS), 0, s, pb);
   return check_launch("projection GEMM");
 }
 
@@ -271,13 +312,18 @@ extern "C" int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n, in
   // serial chain per wave): more waves per CU overlap more of it, fewer operand bytes per flop do not help; 64 x 128
   // tiles (three workgroups per CU) land on the same 53 us.
   if (tile == 0) tile = 5;
+  if (tile == 8)   // the in-workgroup K split needs an even number of 64-deep steps per half
+    for (int i = 0; i < n; ++i)
+      if (problems[i].K % 256 != 0 || problems[i].a_kseg % 128 != 0) tile = 5;
   if (dtype == CAIMAN_BF16)
     return tile == 1 ? launch_proj<bf16_t, 256, 128, 2, 4>(problems, n, s)
          : tile == 3 ? launch_proj<bf16_t, 256, 128, 3, 4>(problems, n, s)
          : tile == 4 ? launch_proj<bf16_t, 256, 128, 2, 8>(problems, n, s)
-         : tile == 5 ? launch_proj<bf16_t, 128, 128, 2, 8>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
+         : tile == 5 ? launch_proj<bf16_t, 128, 128, 2, 8>(problems, n, s)
+         : tile == 8 ? launch_proj<bf16_t, 128, 128, 2, 8, 2>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
   return tile == 1 ? launch_proj<f16_t, 256, 128, 2, 4>(problems, n, s)
        : tile == 3 ? launch_proj<f16_t, 256, 128, 3, 4>(problems, n, s)
        : tile == 4 ? launch_proj<f16_t, 256, 128, 2, 8>(problems, n, s)
-       : tile == 5 ? launch_proj<f16_t, 128, 128, 2, 8>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
+       : tile == 5 ? launch_proj<f16_t, 128, 128, 2, 8>(problems, n, s)
+       : tile == 8 ? launch_proj<f16_t, 128, 128, 2, 8, 2>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
 }

@@ -34,6 +34,8 @@ EARLY_WGRAD = int(__import__("os").environ.get("CAIMAN_EARLY_WGRAD", "1")) != 0
 # projection kernel (csrc/proj_gemm.hip) instead of 2-3 library calls; shapes outside its geometry keep the library path
 PROJ = int(__import__("os").environ.get("CAIMAN_PROJ_GEMM", "1")) != 0
 PROJ_TILE = int(__import__("os").environ.get("CAIMAN_PROJ_TILE", "0"))
+# backward ticks (K = 4H, about one 128 x 128 tile per CU): the variant whose workgroup splits K between two wave groups
+PROJ_TILE_BWD = int(__import__("os").environ.get("CAIMAN_PROJ_TILE_BWD", "8"))
 IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # one launch for all operand images of the weights
 
 
@@ -65,11 +67,11 @@ def _proj_plan(per_tick):
     return np.array(rows, dtype=_PROJ_DT) if rows else None, ranges
 
 
-def _proj_launch(lib, plan, rng, tag, st):
+def _proj_launch(lib, plan, rng, tag, st, tile):
     first, count = rng
     base = plan.ctypes.data
     for i in range(0, count, 8):
-        _lib.check(lib.caiman_proj_gemm(base + (first + i) * _PROJ_DT.itemsize, min(8, count - i), tag, PROJ_TILE, st))
+        _lib.check(lib.caiman_proj_gemm(base + (first + i) * _PROJ_DT.itemsize, min(8, count - i), tag, tile, st))
 
 
 def _skewed(t, first_layer, first_t0, count, n, B, width, chunk, row_offset=0):
@@ -272,7 +274,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             batched = set()
             if use_proj:
                 if ranges[ti][1]:
-                    _proj_launch(lib, plan, ranges[ti], tag, st)
+                    _proj_launch(lib, plan, ranges[ti], tag, st, PROJ_TILE)
                 batched = {l for l, _ in tick}
             elif Wt_post is not None:   # post layers La+1.. with a full chunk this tick: consecutive layers, chunk index falling by one
                 grp = [(l, k) for l, k in tick if La < l < Le and Tl[l] - k * CHb >= CHb]
@@ -440,7 +442,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             batched = set()
             if use_proj:
                 if ranges[ti][1]:
-                    _proj_launch(lib, plan, ranges[ti], tag, st)
+                    _proj_launch(lib, plan, ranges[ti], tag, st, PROJ_TILE_BWD)
                 batched = {l for l, _ in tick}
             elif W_post is not None:   # delta of post layers La..Le-2 with a full chunk: dG of the layer above times its W_ih
                 grp = [(l, k) for l, k in tick if La <= l < Le - 1 and Tl[l] - k * CHb >= CHb]

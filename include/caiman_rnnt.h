@@ -298,7 +298,8 @@ int caiman_lstm_grad_deliver(const caiman_lstm_grad_item_t* items, int n_items, 
  * bf16 / f16 only; N % 128 == 0, K % 128 == 0, a_kseg % 64 == 0, c_nseg % 16 == 0, 16-byte aligned operand rows:
  * caiman_proj_gemm_supported() tells; caiman_proj_gemm() returns CAIMAN_ERR_INVALID for anything else (the caller then
  * keeps the library GEMM).  Put the problems with the longest K first.  tile: 0 = choose (5), 1 = 256 x 128 tiles with two LDS stages, 2 = 128 x 128,
- * 3 = 256 x 128 with three stages (two in flight), 4 = 256 x 128 with 8 waves, 5 = 128 x 128 with 8 waves (measurement variants).
+ * 3 = 256 x 128 with three stages (two in flight), 4 = 256 x 128 with 8 waves, 5 = 128 x 128 with 8 waves,
+ * 8 = 128 x 128 with two groups of 8 waves that split K inside the workgroup (long K, few tiles; needs K % 256 == 0, else 5).
  * ------------------------------------------------------------------------- */
 #define CAIMAN_PROJ_MAX_PROBLEMS 8
 typedef struct {
