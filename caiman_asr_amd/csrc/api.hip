@@ -23,6 +23,6 @@ int check_launch(const char* what) {
 
 }  // namespace caiman
 
-extern "C" int caiman_abi_version(void) { return 4; }
+extern "C" int caiman_abi_version(void) { return 5; }   // 5: + caiman_proj_gemm, caiman_lstm_weight_images, caiman_lstm_grad_deliver, caiman_lstm_resident_xcd_roles; caiman_lstm_prepare accepts R = NULL and gate_layout bit 1
 extern "C" const char* caiman_last_error(void) { return caiman::g_err; }
 extern "C" int caiman_built_for_gfx950(void) { return 1; }
