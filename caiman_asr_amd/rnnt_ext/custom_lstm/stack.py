@@ -37,6 +37,7 @@ def _chunk(L, T=None):
     return CHUNK_DEEP if L >= 4 else CHUNK
 IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # csrc/lstm_images.hip: one launch for all weight images
 INTERLEAVED = 1  # gate layout used INSIDE the pipeline: [.., H, 4] (see include/caiman_rnnt.h)
+RINGS_ZEROED = 2  # caiman_lstm_prepare(gate_layout | RINGS_ZEROED): the caller has cleared ring / dC itself (one memset for all layers)
 
 
 def _perm_rows(w, H):
