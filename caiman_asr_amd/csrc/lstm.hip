@@ -22,6 +22,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -550,7 +551,8 @@ struct FastAct<false> : Act<float, false> {
 // collective waits for the slowest rank.
 constexpr int kResTimeoutTicks = 500000000;
 constexpr int kResCounterStride = 32;       // one 128-byte line per slot counter
-constexpr int kRes2CtrPerSlot = 12;          // 2-D split backward kernel: qc[4] + gc[8] per slot
+constexpr int kRes2MaxGroups = 12;           // 2-D split backward kernel: groups of 128 columns per layer (H <= 1536)
+constexpr int kRes2CtrPerSlot = 4 + kRes2MaxGroups;   // its counters per slot: qc[4] + gc[groups]
 constexpr int kResMaxTiles = 4;              // batch-tile kernels: 32-row tiles per workgroup
 // a launch's counter block (+ the abort word): 12 counters per slot for the 2-D split backward kernel, one for the others
 constexpr size_t kResSyncBytes = (size_t)(kMaxSlots * kRes2CtrPerSlot + 1) * kResCounterStride * sizeof(unsigned);
@@ -1083,6 +1085,238 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, in
   }
 }
 
+// Forward resident kernel with the h row gathered by LDS-DMA (H = 512, 1024, 1536): lstm_fwd_resident pulls the row
+// through staging registers (32 * H / 8 / 256 16-byte pieces per thread: 96 VGPRs at H = 1536), which, next to
+// 2 * H / 32 resident weight fragments per wave (384 VGPRs at H = 1536), does not fit the 512 registers of a wave.  Here
+// the row goes straight from L2 into LDS (`global_load_lds_dwordx4 ... sc1`, one 1 KB piece = 512 columns of one batch
+// row per wave instruction) in H / 512 stages, each with its own LDS object, and the MFMAs of stage q run while the
+// later stages are still in flight -- the gather of lstm_bwd_resident2.  Everything else (roles, hand-off protocol,
+// cell update, stores) is lstm_fwd_resident's.  LDS-DMA cannot leave rows out: rows >= B read row B - 1 again and
+// their results are never stored.  A layer of H = 1536 takes 48 workgroups, so five layers share the chip
+// (try_fwd_resident splits a tick's slots into groups that fit).
+template <typename T, bool HARD, int NKS, bool PROF, int KBW = 1>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_resident_dma(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host, unsigned* scrub) {
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32;
+  constexpr int NST = H / 512;                             // LDS-DMA stages of 512 columns
+  constexpr int LDW = 512 + 8;                             // +16 bytes: the 16 lanes of a b128 read hit distinct banks
+  constexpr int KPS = 16;                                  // k-steps per stage
+  static_assert(H % 512 == 0 && NST >= 1 && NST <= 3, "DMA forward kernel: H = 512, 1024 or 1536");
+  __shared__ __attribute__((aligned(16))) T ring0[32 * LDW], ring1[NST > 1 ? 32 * LDW : 8], ring2[NST > 2 ? 32 * LDW : 8];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tr = reinterpret_cast<T*>(smem);                       // [4 waves][2: h, c][32 rows][8 units]
+  int* flag = reinterpret_cast<int*>(tr + 4 * 2 * 32 * 8);  // abort broadcast
+  auto ring = [&](int k) -> T* { return k == 0 ? ring0 : (k == 1 ? ring1 : ring2); };
+
+  int slot, j;
+  res_role<NKS>(slot, j);
+  const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytes / sizeof(unsigned)));
+  if (nsteps <= 0) return;
+  const int nwg = NKS;
+  unsigned* cnt = sync + slot * kResCounterStride;
+  unsigned* fail_dev = sync + kMaxSlots * kRes2CtrPerSlot * kResCounterStride;
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int u0 = j * 32 + wave * 8;   // first hidden unit of this wave
+
+  // resident A fragments: row m of a 16-row tile = (unit m>>2, gate m&3); tile_R_fwd_kernel stores n = gate*4 + unit
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rtile[slot];
+    const int n = (r & 3) * 4 + (r >> 2);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)j * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) wreg[rt][s] = *reinterpret_cast<const frag*>(Rt + ((blk * NKS + s) * 16 + n) * 32 + 8 * kq);
+    }
+  }
+  // this lane's cells: unit u0 + rt*4 + kq, batch row ct*16 + r
+  float creg[2][2];
+  g4 gcur[2][2], gnext[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gcur[i >> 1][i & 1][q] = static_cast<T>(0.f);
+  {
+    const T* c0 = w.c[slot];
+    const T* g = w.g[slot];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = ct * 16 + r, u = u0 + rt * 4 + kq;
+        creg[rt][ct] = b < B ? static_cast<float>(c0[(int64_t)b * H + u]) : 0.f;
+        if (b < B) gcur[rt][ct] = *reinterpret_cast<const g4*>(g + ((int64_t)b * H + u) * 4);
+        gnext[rt][ct] = gcur[rt][ct];
+      }
+  }
+  if (tid == 0) *flag = 0;
+  T* trh = tr + wave * (2 * 32 * 8);
+  T* trc = trh + 32 * 8;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+
+  const bool prof = PROF && tid == 0 && slot == 0 && j == 0;
+  long long tp[5] = {0, 0, 0, 0, 0}, pt = 0;
+  if (prof) pt = wall_clock64();
+  for (int s = 0; s < nsteps; ++s) {
+    T* g = w.g[slot] + go * s;
+    if (s + 1 < nsteps) {   // next step's pre-activations: independent of h, in flight across the wait
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int b = ct * 16 + r, u = u0 + rt * 4 + kq;
+          if (b < B) gnext[rt][ct] = *reinterpret_cast<const g4*>(g + go + ((int64_t)b * H + u) * 4);
+        }
+    }
+    if (s > 0 && tid == 0) {
+      if (!res_wait(cnt, (unsigned)nwg * (unsigned)s, fail_dev, fail_host)) *flag = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+    if (*flag) break;
+    CAIMAN_PROF_MARK(0)
+    // h of this step: row s of y, [B][H] row-major -> LDS by DMA (sc1: the loads of handed-off bytes bypass the
+    // non-coherent levels, visibility table, first row).  8 instructions per wave and stage: the vmcnt arithmetic
+    // below counts them.
+    {
+      const T* src = w.y[slot] + so * s;
+#pragma unroll
+      for (int q = 0; q < NST; ++q) {
+        T* bq = ring(q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int b = wave + 4 * i, bs = b < B ? b : B - 1;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(src + (int64_t)bs * H + q * 512 + lane * 8),
+              (__attribute__((address_space(3))) void*)(bq + b * LDW), 16, 0, 16);
+        }
+      }
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      // this wave's rows of stage q have landed (the later stages' 8 instructions each may still fly) and its LDS reads
+      // of the stage before have returned; behind the bare barrier that holds for every wave
+      if (q + 2 < NST) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (q == NST - 1) { CAIMAN_PROF_MARK(1) }
+      const T* bq = ring(q);
+      constexpr int KB = NKS > 32 ? KBW : 4, NB_ = KPS / KB;
+      frag bb[2][KB][2];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        bb[0][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + i * 32 + kq * 8);
+        bb[0][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + i * 32 + kq * 8);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB_; ++nb) {
+        if (nb + 1 < NB_) {
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (nb + 1) * KB + i;
+            bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + ks * 32 + kq * 8);
+            bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + ks * 32 + kq * 8);
+          }
+        }
+        // the MFMAs below take their operands from this asm, so they cannot be hoisted back above the reads just issued
+        if constexpr (KB == 4)
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                       :: "memory");
+        else if constexpr (KB == 2)
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1])
+                       :: "memory");
+        else
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const int ks = q * KPS + nb * KB + i;
+          acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+          acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+          acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+          acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+        }
+      }
+    }
+    // cell update, lane-local: acc register q = gate q of (unit kq of the row tile, batch row r of the column tile)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = ct * 16 + r, ul = rt * 4 + kq;
+        const float pi = static_cast<float>(gcur[rt][ct][0]) + acc[rt][ct][0];
+        const float pf = static_cast<float>(gcur[rt][ct][1]) + acc[rt][ct][1];
+        const float pg = static_cast<float>(gcur[rt][ct][2]) + acc[rt][ct][2];
+        const float po = static_cast<float>(gcur[rt][ct][3]) + acc[rt][ct][3];
+        const float ig = FastAct<HARD>::sigm(pi), fg = FastAct<HARD>::sigm(pf);
+        const float gg = FastAct<HARD>::tanhv(pg), og = FastAct<HARD>::sigm(po);
+        const float c = ig * gg + fg * creg[rt][ct];
+        const T cv = static_cast<T>(c);
+        const T yv = static_cast<T>(og * FastAct<HARD>::tanhv(c));
+        creg[rt][ct] = static_cast<float>(cv);
+        trh[b * 8 + ul] = yv;
+        trc[b * 8 + ul] = cv;
+        if (b < B) {
+          g4 v;
+          v[0] = static_cast<T>(ig); v[1] = static_cast<T>(fg); v[2] = static_cast<T>(gg); v[3] = static_cast<T>(og);
+          *reinterpret_cast<g4*>(g + ((int64_t)b * H + u0 + ul) * 4) = v;
+        }
+        gcur[rt][ct] = gnext[rt][ct];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      // lane -> (batch row lane>>1, 4 units): one 8-byte piece of the h row (write-through) and of the c row
+      const int b = lane >> 1, half = lane & 1;
+      if (b < B) {
+        const g4 hv = *reinterpret_cast<const g4*>(trh + b * 8 + half * 4);
+        const g4 cv = *reinterpret_cast<const g4*>(trc + b * 8 + half * 4);
+        const int64_t e = (int64_t)b * H + u0 + half * 4;
+        unsigned long long hbits;
+        __builtin_memcpy(&hbits, &hv, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(w.y[slot] + so * (s + 1) + e), hbits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
+        if (w.ymask[slot]) {
+          g4 mv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
+            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
+          }
+          *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
+        }
+        if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
+          const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+          T* h_out = w.hring[slot] + ((w.parity[slot] + nsteps) & 1) * hsz;
+          *reinterpret_cast<g4*>(h_out + tiled_index(b, u0 + half * 4, NKS)) = hv;
+        }
+      }
+    }
+    CAIMAN_PROF_MARK(2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CAIMAN_PROF_MARK(3)
+  }
+  if (prof) {
+    for (int i = 0; i < 4; ++i)
+      __hip_atomic_fetch_add(fail_host + kResProfFwd + i, (unsigned)tp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfFwd + 4, (unsigned)nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Backward counterpart: dh[t] = delta[t] + dG[t+1]·R with K = 4H.  A workgroup owns 32 hidden units and keeps the
 // matching 32 columns of R (as rows of Rᵀ, all 4H of K: again 256 KB at H = 1024) in registers: wave (rt, kh) holds
 // the 16-unit row tile rt for half of the k-steps.  The operand every workgroup needs is the whole dG row of the
@@ -1414,10 +1648,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
 // only by the XCDs that need it (2.1x -> ~1x HBM-side traffic).  Placement only changes the speed.
 // Sums are fp32 throughout: four K-quarter partials added in a fixed order (deterministic run to run).
 // ===========================================================================
-constexpr size_t kRes2PartialFloatsPerSlot = (size_t)2 * 8 * 16 * 1024;   // [parity][jq <= 8][dst 4][src 4][32 x 32]
+constexpr size_t kRes2PartialFloatsPerSlot = (size_t)2 * kRes2MaxGroups * 16 * 1024;   // [parity][jq][dst 4][src 4][32 x 32]
 constexpr int kResProfBwd2 = 16;                        // fail_host words [16, 24): six phase sums, unused, timesteps
 
-template <typename T, bool HARD, int NKS, bool PROF>
+template <typename T, bool HARD, int NKS, bool PROF, int KBW = 1>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host,
                                                              float* pws, unsigned* scrub) {
   using frag = typename frag8<T>::type;
@@ -1427,12 +1661,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
   constexpr int LDW = 512 + 8;
   constexpr int KPS = 16;                                // k-steps per stage
   constexpr int PPQ = NKS / 4;                           // workgroups that finalise units of one K quarter
-  static_assert(H % 512 == 0 && NST >= 1 && NST <= 2, "2-D split kernel: H = 512 or 1024");
-  __shared__ __attribute__((aligned(16))) T ring0[32 * LDW], ring1[NST > 1 ? 32 * LDW : 8];
+  static_assert(H % 512 == 0 && NST >= 1 && NST <= 3 && NKS / 4 <= kRes2MaxGroups, "2-D split kernel: H = 512, 1024 or 1536");
+  __shared__ __attribute__((aligned(16))) T ring0[32 * LDW], ring1[NST > 1 ? 32 * LDW : 8], ring2[NST > 2 ? 32 * LDW : 8];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ownp = reinterpret_cast<float*>(smem);          // [32 batch][32 units + 4]: this workgroup's own partial block
   int* flag = reinterpret_cast<int*>(ownp + 32 * 36);
-  auto ring = [&](int k) -> T* { return k == 0 ? ring0 : ring1; };
+  // H = 1536: 384 of a wave's 512 registers hold weights; the 16 running bias-gradient sums of a thread live in LDS
+  // ([sum][thread]: conflict-free), not in registers (res_bwd2_lds sizes the dynamic part)
+  constexpr bool BSUM_LDS = NKS > 32;
+  float* bs_l = reinterpret_cast<float*>(flag + 4) + threadIdx.x;
+  auto ring = [&](int k) -> T* { return k == 0 ? ring0 : (k == 1 ? ring1 : ring2); };
 
   int slot, bx;
   res_role<NKS>(slot, bx);
@@ -1464,13 +1702,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
   // epilogue role (as in lstm_bwd_resident with j = bx): batch row eb, units u .. u+3
   const int eb = tid >> 3, ul4 = (tid & 7) * 4, u = bx * 32 + ul4;
   const bool ep = eb < B;
-  const int64_t eoff = (int64_t)eb * H + u;
+  const unsigned eoff = (unsigned)(eb * H + u);   // 32-bit lane offsets against wave-uniform row pointers
   float dcs[4] = {0.f, 0.f, 0.f, 0.f};
   float bsum[4][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bsum[q][e] = 0.f;
+    for (int e = 0; e < 4; ++e) {
+      bsum[q][e] = 0.f;
+      if constexpr (BSUM_LDS) bs_l[(q * 4 + e) * 256] = 0.f;
+    }
   if (ep) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoff);
 #pragma unroll
@@ -1500,8 +1741,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
     frag gv0, gv1;
     g4 cpv, ccv, dlv;
     if (ep) {   // none of these depends on the recurrence: they travel while the workgroup waits
-      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4);
-      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4 + 8);
+      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4u);
+      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4u + 8u);
       cpv = *reinterpret_cast<const g4*>(c_prev + eoff);
       ccv = *reinterpret_cast<const g4*>(c_prev + so + eoff);
       dlv = *reinterpret_cast<const g4*>(delta + (int64_t)eb * d_sb + u);
@@ -1539,10 +1780,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       for (int q = 0; q < NST; ++q) {
         // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
         // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
-        if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (q + 2 < NST) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const T* bq = ring(q);
-        constexpr int KB = 4, NB_ = KPS / KB;
+        constexpr int KB = NKS > 32 ? KBW : 4, NB_ = KPS / KB;   // H = 1536: 384 weight registers leave room for one or two k-steps ahead
         frag bb[2][KB][2];
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
@@ -1560,9 +1802,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
             }
           }
           // the MFMAs take their operands from this asm: they cannot be hoisted above the reads just issued
-          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
-                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
-                       :: "memory");
+          if constexpr (KB == 4)
+            asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                              "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                         :: "memory");
+          else if constexpr (KB == 2)
+            asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1])
+                         :: "memory");
+          else
+            asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]) :: "memory");
 #pragma unroll
           for (int i = 0; i < KB; ++i) {
             const int ks = q * KPS + nb * KB + i;
@@ -1577,7 +1825,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       // ---- hand the partial block of columns [128 jq + 32 wave, +32) to the member that finalises them ----------------
       // C layout: column lane & 15 = batch row of the column tile, row kg * 4 + reg = unit of the row tile
       const int round = s - (has_in0 ? 0 : 1);
-      float* pround = pslot + ((size_t)(round & 1) * 8 + jq) * (16 * 1024);
+      float* pround = pslot + ((size_t)(round & 1) * kRes2MaxGroups + jq) * (16 * 1024);
       if (wave == kq) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -1640,15 +1888,20 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
         vG[q] = static_cast<T>(dc * gi * FastAct<HARD>::tanh_prime(gg));
         vO[q] = static_cast<T>(dy * ct * FastAct<HARD>::sigm_prime(go_));
         dcs[q] = dc * gf;
-        bsum[q][0] += static_cast<float>(vI[q]); bsum[q][1] += static_cast<float>(vF[q]);
-        bsum[q][2] += static_cast<float>(vG[q]); bsum[q][3] += static_cast<float>(vO[q]);
+        if constexpr (BSUM_LDS) {
+          bs_l[(q * 4 + 0) * 256] += static_cast<float>(vI[q]); bs_l[(q * 4 + 1) * 256] += static_cast<float>(vF[q]);
+          bs_l[(q * 4 + 2) * 256] += static_cast<float>(vG[q]); bs_l[(q * 4 + 3) * 256] += static_cast<float>(vO[q]);
+        } else {
+          bsum[q][0] += static_cast<float>(vI[q]); bsum[q][1] += static_cast<float>(vF[q]);
+          bsum[q][2] += static_cast<float>(vG[q]); bsum[q][3] += static_cast<float>(vO[q]);
+        }
       }
       frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
       o0[0] = vI[0]; o0[1] = vF[0]; o0[2] = vG[0]; o0[3] = vO[0]; o0[4] = vI[1]; o0[5] = vF[1]; o0[6] = vG[1]; o0[7] = vO[1];
       o1[0] = vI[2]; o1[1] = vF[2]; o1[2] = vG[2]; o1[3] = vO[2]; o1[4] = vI[3]; o1[5] = vF[3]; o1[6] = vG[3]; o1[7] = vO[3];
       const __amdgpu_buffer_rsrc_t ro = res_rsrc(dG);
-      res_store16(o0, ro, (int)(eoff * 4) * (int)sizeof(T));
-      res_store16(o1, ro, (int)(eoff * 4 + 8) * (int)sizeof(T));
+      res_store16(o0, ro, (int)(eoff * 4u) * (int)sizeof(T));
+      res_store16(o1, ro, (int)(eoff * 4u + 8u) * (int)sizeof(T));
       if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
         const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
         T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
@@ -1668,6 +1921,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
   }
   if (w.dbias[slot] && !*flag) {   // as in lstm_bwd_resident: rows wave * 8 + lane / 8 hold the same units
     float* red = ownp;
+    if constexpr (BSUM_LDS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[q][e] = bs_l[(q * 4 + e) * 256];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1864,7 +2123,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
       // ---- hand the partial block of columns [128 jq + 32 wave, +32) to the member that finalises them ----------------
       // C layout: column lane & 15 = batch row of the column tile, row kg * 4 + reg = unit of the row tile
       const int round = s - (has_in0 ? 0 : 1);
-      float* pround = pslot + ((size_t)(round & 1) * 8 + jq) * (16 * 1024);
+      float* pround = pslot + ((size_t)(round & 1) * kRes2MaxGroups + jq) * (16 * 1024);
       if (wave == kq) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -2149,28 +2408,77 @@ ResState* res_state() {
 template <typename T>
 inline size_t res_fwd_lds(int H) { return (size_t)(32 * (H + 8) + 4 * 2 * 32 * 8) * sizeof(T) + 16; }
 
+// A tick's slots are independent recurrences (each layer works on its own chunk): when they do not fit the chip together
+// (H = 1536: 48 workgroups per layer, five layers per launch) they go out as consecutive resident launches.
+template <typename S>
+inline S res_slot_group(const S& w, int first, int count) {
+  S g{};
+  g.seed = w.seed;
+  auto cp = [&](auto S::*field) {
+    for (int i = 0; i < count; ++i) (g.*field)[i] = (w.*field)[first + i];
+  };
+  if constexpr (std::is_same<S, FwdSlots<bf16_t>>::value || std::is_same<S, FwdSlots<f16_t>>::value) {
+    cp(&S::Rtile); cp(&S::g); cp(&S::c); cp(&S::y); cp(&S::hring); cp(&S::parity); cp(&S::nsteps); cp(&S::ymask);
+    cp(&S::drop_base); cp(&S::drop_p); cp(&S::hidden);
+  } else {
+    cp(&S::Rttile); cp(&S::g); cp(&S::c); cp(&S::delta); cp(&S::d_st); cp(&S::d_sb); cp(&S::dG); cp(&S::dring); cp(&S::dC);
+    cp(&S::parity); cp(&S::nsteps); cp(&S::has_in0); cp(&S::drop_base); cp(&S::drop_p); cp(&S::hidden); cp(&S::dbias);
+  }
+  return g;
+}
+
+// the DMA-gather forward kernel: the only one for H = 1536; for H = 512 / 1024 an A/B switch (CAIMAN_LSTM_FWD_DMA=1)
+inline bool res_fwd_use_dma(int nks) {
+  static const bool forced = std::getenv("CAIMAN_LSTM_FWD_DMA") != nullptr && std::atoi(std::getenv("CAIMAN_LSTM_FWD_DMA")) != 0;
+  return nks == 48 || (forced && (nks == 16 || nks == 32));
+}
+inline int res_wide_kb() {   // LDS reads issued ahead of the MFMAs in the H = 1536 kernels: 1 k-step (no spills) or 2
+  static const int kb = std::getenv("CAIMAN_LSTM_WIDE_KB") ? std::atoi(std::getenv("CAIMAN_LSTM_WIDE_KB")) : 1;
+  return kb == 2 ? 2 : 1;
+}
+
 // true when the launch was taken by the resident kernel
 template <typename T, bool HARD>
-bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+bool try_fwd_resident(const FwdSlots<T>& w_all, int n_slots_all, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
   *err = CAIMAN_OK;
   if (!g_res_mode.load(std::memory_order_relaxed) || B > 32 || n_launches < 2) return false;
-  for (int i = 0; i < n_slots; ++i)
-    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;   // one width per launch
+  for (int i = 0; i < n_slots_all; ++i)
+    if ((w_all.hidden[i] ? w_all.hidden[i] : (int)H) != (int)H) return false;   // one width per launch
   const int nks = (int)(H / 32);
-  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return false;
+  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32 || nks == 48)) return false;
   ResState* st = res_state();
-  if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  if (!st || nks > st->cus) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;   // a hand-off has timed out in this process: stay on the per-timestep kernels
-  unsigned* scrub = nullptr;
-  unsigned* sync = res_begin(st, s, &scrub);
-  const dim3 grid = res_grid(nks, n_slots, st->cus);
-  const size_t lds = res_fwd_lds<T>((int)H);
+  const int per_launch = st->cus / nks;
+  const bool dma = res_fwd_use_dma(nks);
+  const int mode = g_res_mode.load(std::memory_order_relaxed);
+  for (int first = 0; first < n_slots_all; first += per_launch) {
+    const int n_slots = std::min(per_launch, n_slots_all - first);
+    const FwdSlots<T> w = (first == 0 && n_slots == n_slots_all) ? w_all : res_slot_group(w_all, first, n_slots);
+    unsigned* scrub = nullptr;
+    unsigned* sync = res_begin(st, s, &scrub);
+    const dim3 grid = res_grid(nks, n_slots, st->cus);
+    if (dma) {
+      const size_t lds = (size_t)(4 * 2 * 32 * 8) * sizeof(T) + 16;   // the row buffers are static LDS objects of the kernel
+#define CAIMAN_RESD(NKV, KBV)                                                                                        \
+  do {                                                                                                               \
+    if (mode == 2) hipLaunchKernelGGL((lstm_fwd_resident_dma<T, HARD, NKV, true, KBV>), grid, dim3(256), lds, s, w, (int)B, \
+                                      sync, st->fail_host, scrub);                                                   \
+    else hipLaunchKernelGGL((lstm_fwd_resident_dma<T, HARD, NKV, false, KBV>), grid, dim3(256), lds, s, w, (int)B, sync,    \
+                            st->fail_host, scrub);                                                                   \
+  } while (0)
+      if (nks == 16) CAIMAN_RESD(16, 1);
+      else if (nks == 32) CAIMAN_RESD(32, 1);
+      else if (res_wide_kb() == 2) CAIMAN_RESD(48, 2);
+      else CAIMAN_RESD(48, 1);
+#undef CAIMAN_RESD
+    } else {
+      const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RES(NKV)                                                                                              \
   do {                                                                                                               \
-    auto kern = g_res_mode.load(std::memory_order_relaxed) == 2 ? lstm_fwd_resident<T, HARD, NKV, true>               \
-                                                                : lstm_fwd_resident<T, HARD, NKV, false>;             \
+    auto kern = mode == 2 ? lstm_fwd_resident<T, HARD, NKV, true> : lstm_fwd_resident<T, HARD, NKV, false>;           \
     static bool attr_set[2][16] = {};   /* per device: the attribute belongs to the device's code object */         \
-    bool& attr_done = attr_set[g_res_mode.load(std::memory_order_relaxed) == 2][st->dev];                            \
+    bool& attr_done = attr_set[mode == 2][st->dev];                                                                  \
     if (!attr_done) {                                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)res_fwd_lds<T>(NKV * 32)) != hipSuccess) {                                        \
@@ -2181,17 +2489,20 @@ bool try_fwd_resident(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t
     }                                                                                                                \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, scrub);                                \
   } while (0)
-  switch (nks) {
-    case 2: CAIMAN_RES(2); break;
-    case 4: CAIMAN_RES(4); break;
-    case 8: CAIMAN_RES(8); break;
-    case 16: CAIMAN_RES(16); break;
-    case 24: CAIMAN_RES(24); break;
-    default: CAIMAN_RES(32); break;
-  }
+      switch (nks) {
+        case 2: CAIMAN_RES(2); break;
+        case 4: CAIMAN_RES(4); break;
+        case 8: CAIMAN_RES(8); break;
+        case 16: CAIMAN_RES(16); break;
+        case 24: CAIMAN_RES(24); break;
+        default: CAIMAN_RES(32); break;
+      }
 #undef CAIMAN_RES
-  res_end(st, s);
-  *err = check_launch("lstm resident forward");
+    }
+    res_end(st, s);
+    *err = check_launch("lstm resident forward");
+    if (*err != CAIMAN_OK) return true;
+  }
   return true;
 }
 
@@ -2254,40 +2565,49 @@ bool try_bwd_resident(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t
   return true;
 }
 
-// 2-D split variant (lstm_bwd_resident2): same admission rules, H = 512 or 1024 only
+// 2-D split variant (lstm_bwd_resident2): same admission rules, H = 512, 1024 or 1536 (the latter in slot groups that
+// fit the chip, as in try_fwd_resident)
 template <typename T, bool HARD>
-bool try_bwd_resident2(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+bool try_bwd_resident2(const BwdSlots<T>& w_all, int n_slots_all, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
   *err = CAIMAN_OK;
-  if (!g_res_mode.load(std::memory_order_relaxed) || !g_res_bwd_split.load(std::memory_order_relaxed) || B > 32 ||
-      n_launches < 2)
-    return false;
-  if (H != 512 && H != 1024) return false;
-  for (int i = 0; i < n_slots; ++i) {
-    if ((w.hidden[i] ? w.hidden[i] : (int)H) != (int)H) return false;
-    if ((reinterpret_cast<uintptr_t>(w.delta[i]) & 7u) || (w.d_sb[i] & 3) || (w.d_st[i] & 3) ||
-        (reinterpret_cast<uintptr_t>(w.dC[i]) & 15u))
+  if (!g_res_mode.load(std::memory_order_relaxed) || B > 32 || n_launches < 2) return false;
+  if (H != 1536 && !g_res_bwd_split.load(std::memory_order_relaxed)) return false;   // H = 1536 has no whole-row kernel
+  if (H != 512 && H != 1024 && H != 1536) return false;
+  for (int i = 0; i < n_slots_all; ++i) {
+    if ((w_all.hidden[i] ? w_all.hidden[i] : (int)H) != (int)H) return false;
+    if ((reinterpret_cast<uintptr_t>(w_all.delta[i]) & 7u) || (w_all.d_sb[i] & 3) || (w_all.d_st[i] & 3) ||
+        (reinterpret_cast<uintptr_t>(w_all.dC[i]) & 15u))
       return false;
   }
   const int nks = (int)(H / 32);
   ResState* st = res_state();
-  if (!st || (int64_t)n_slots * nks > st->cus) return false;
+  if (!st || nks > st->cus) return false;
   if (*reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return false;
-  unsigned* scrub = nullptr;
-  unsigned* sync = res_begin(st, s, &scrub);
-  const dim3 grid = res_grid(nks, n_slots, st->cus);
-  const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
+  const int per_launch = st->cus / nks;
   const bool prof = g_res_mode.load(std::memory_order_relaxed) == 2;
-#define CAIMAN_RES2(NKV)                                                                                             \
+  for (int first = 0; first < n_slots_all; first += per_launch) {
+    const int n_slots = std::min(per_launch, n_slots_all - first);
+    const BwdSlots<T> w = (first == 0 && n_slots == n_slots_all) ? w_all : res_slot_group(w_all, first, n_slots);
+    unsigned* scrub = nullptr;
+    unsigned* sync = res_begin(st, s, &scrub);
+    const dim3 grid = res_grid(nks, n_slots, st->cus);
+    const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16 + (nks > 32 ? (size_t)16 * 256 * sizeof(float) : 0);
+#define CAIMAN_RES2(NKV, KBV)                                                                                        \
   do {                                                                                                               \
-    if (prof) hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, true>), grid, dim3(256), lds, s, w, (int)B, sync,  \
-                                 st->fail_host, st->partials, scrub);                                                      \
-    else hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, false>), grid, dim3(256), lds, s, w, (int)B, sync,     \
-                            st->fail_host, st->partials, scrub);                                                           \
+    if (prof) hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, true, KBV>), grid, dim3(256), lds, s, w, (int)B, sync, \
+                                 st->fail_host, st->partials, scrub);                                                \
+    else hipLaunchKernelGGL((lstm_bwd_resident2<T, HARD, NKV, false, KBV>), grid, dim3(256), lds, s, w, (int)B, sync,    \
+                            st->fail_host, st->partials, scrub);                                                     \
   } while (0)
-  if (nks == 16) CAIMAN_RES2(16); else CAIMAN_RES2(32);
+    if (nks == 16) CAIMAN_RES2(16, 1);
+    else if (nks == 32) CAIMAN_RES2(32, 1);
+    else if (res_wide_kb() == 2) CAIMAN_RES2(48, 2);
+    else CAIMAN_RES2(48, 1);
 #undef CAIMAN_RES2
-  res_end(st, s);
-  *err = check_launch("lstm resident backward (2-D split)");
+    res_end(st, s);
+    *err = check_launch("lstm resident backward (2-D split)");
+    if (*err != CAIMAN_OK) return true;
+  }
   return true;
 }
 
@@ -2591,9 +2911,11 @@ extern "C" int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots)
   if (!g_res_mode.load(std::memory_order_relaxed) || B < 1 || H % 32 != 0 || n_slots < 1 || n_slots > kMaxSlots) return 0;
   if (B > 32 && (B > 32 * kResMaxTiles || (H != 512 && H != 1024))) return 0;   // batch tiles: the backward kernel's shapes
   const int nks = (int)(H / 32);
-  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32)) return 0;
+  if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32 || nks == 48)) return 0;
   ResState* st = res_state();
-  return (st && (int64_t)n_slots * nks <= st->cus && *reinterpret_cast<volatile unsigned*>(st->fail_host) == 0u) ? 1 : 0;
+  if (!st || *reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return 0;
+  // B <= 32: slots that do not fit the chip together go out as consecutive launches; the batch-tile kernels do not split
+  return (B <= 32 ? nks <= st->cus : (int64_t)n_slots * nks <= st->cus) ? 1 : 0;
 }
 
 // Wave calls served by a resident launch since the library was loaded (callers that account launches and bytes

@@ -1,46 +1,79 @@
-"""YAML model-config loading + signature validation.
-Mirror of training/caiman_asr_train/rnnt/config.py:31-75,136-142: the unchanged
-training/configs/*.yaml of the reference load here, and unknown `rnnt:` keys are rejected
-against the RNNT constructor signature."""
+"""YAML model-config loading + validation against a constructor signature.
+
+Surface of training/caiman_asr_train/rnnt/config.py:31-75,136-142 (`default_args`, `load`, `validate_and_fill`,
+`rnnt`): the unchanged training/configs/*.yaml of the reference load here, anchors are expanded into independent
+copies, and a key of the `rnnt:` section that the RNNT constructor does not take is rejected with the reference's
+wording ("Unknown parameter ...", "Value for ... not specified ...").  The bodies are this repo's own: the signature
+is bound once into a table of (name, default) pairs, the user keys are classified against it in one pass.
+"""
+import copy
 import inspect
-from pathlib import Path
-from typing import Dict
+import os
+from typing import Dict, Iterable
 
 import yaml
 
+_REQUIRED = inspect.Parameter.empty
+
+
+def _signature_table(klass):
+    """[(keyword, default | _REQUIRED)] of klass.__init__, `self` and *args / **kwargs catch-alls left out."""
+    table = []
+    for name, par in list(inspect.signature(klass.__init__).parameters.items())[1:]:
+        if par.kind in (inspect.Parameter.VAR_POSITIONAL, inspect.Parameter.VAR_KEYWORD):
+            continue
+        table.append((name, par.default))
+    return table
+
 
 def default_args(klass) -> Dict:
-    sig = inspect.signature(klass.__init__)
-    return {k: v.default for k, v in sig.parameters.items() if k != "self"}
+    return dict(_signature_table(klass))
 
 
 def load(fpath) -> Dict:
-    fpath = str(fpath)
-    if fpath.endswith(".toml"):
-        raise ValueError(".toml config format has been changed to .yaml")
-    if Path(fpath).stat().st_size == 0:
-        raise ValueError(f"Config file {fpath} is empty")
-    cfg = yaml.safe_load(open(fpath, "r"))
-
-    class _NoAlias(yaml.SafeDumper):
-        def ignore_aliases(self, data):
-            return True
-
-    return yaml.safe_load(yaml.dump(cfg, Dumper=_NoAlias))  # deep-copies anchor-shared nodes
+    path = os.fspath(fpath)
+    if os.path.splitext(path)[1] == ".toml":
+        raise ValueError(f"{path}: the .toml config format was replaced by .yaml")
+    if os.path.getsize(path) == 0:
+        raise ValueError(f"{path}: config file is empty")
+    with open(path, "r") as fh:
+        tree = yaml.safe_load(fh)
+    # YAML anchors (`&x` / `*x`, `<<: *x`) load as ONE shared object per anchor: give every user its own copy, so that
+    # editing cfg["a"] after loading can never leak into cfg["b"]
+    return copy.deepcopy(tree, memo=_NoSharing())
 
 
-def validate_and_fill(klass, user_conf, ignore=(), optional=(), deprecated=()):
-    conf = default_args(klass)
-    to_ignore = set(ignore).union(deprecated)
-    for k, v in user_conf.items():
-        assert k in conf or k in to_ignore, f"Unknown parameter {k} for {klass}"
-        if k in deprecated:
+class _NoSharing(dict):
+    """deepcopy memo that forgets: a node reached twice is copied twice."""
+
+    def __setitem__(self, key, value):
+        pass
+
+    def get(self, key, default=None):
+        return default
+
+
+def validate_and_fill(klass, user_conf, ignore: Iterable[str] = (), optional: Iterable[str] = (),
+                      deprecated: Iterable[str] = ()) -> Dict:
+    """keyword dict for klass(**...): constructor defaults overlaid with `user_conf`.  Keys outside the signature must
+    be listed in `ignore` / `deprecated` (deprecated keys are dropped); a parameter without default that the user did
+    not give is an error unless it is `optional` (then it is left for the caller to supply)."""
+    table = _signature_table(klass)
+    known = {name for name, _ in table}
+    passthrough, dropped = set(ignore), set(deprecated)
+    strays = [k for k in user_conf if k not in known and k not in passthrough and k not in dropped]
+    assert not strays, f"Unknown parameter {strays[0]} for {klass}"
+    out = {}
+    for name, default in table:
+        value = user_conf[name] if (name in user_conf and name not in dropped) else default
+        if value is _REQUIRED:
+            assert name in optional, f"Value for {name} not specified for {klass}"
             continue
-        conf[k] = v
-    conf = {k: v for k, v in conf.items() if k not in optional or v is not inspect.Parameter.empty}
-    for k, v in conf.items():
-        assert v is not inspect.Parameter.empty, f"Value for {k} not specified for {klass}"
-    return conf
+        out[name] = value
+    for k in user_conf:           # keys the caller asked to carry along although the constructor does not take them
+        if k in passthrough and k not in dropped and k not in known:
+            out[k] = user_conf[k]
+    return out
 
 
 def rnnt(conf) -> Dict:

@@ -64,7 +64,19 @@ def _proj_plan(per_tick):
         probs.sort(key=lambda r: -r[6])     # longest K first: the long tiles start first, the short ones fill in
         ranges.append((len(rows), len(probs)))
         rows += probs
-    return np.array(rows, dtype=_PROJ_DT) if rows else None, ranges
+    if not rows:
+        return None, ranges
+    plan = np.array(rows, dtype=_PROJ_DT)
+    # caiman_proj_gemm() rejects operands it cannot address with 16-byte accesses; every operand here is a buffer this
+    # module allocated itself at offsets that are multiples of a row, so a violation is a bug in the plan, not a shape to
+    # fall back on: say so now, before the first launch of the pass, instead of CAIMAN_ERR_INVALID in the middle of it
+    bad = ((plan["a"] % 16 != 0) | (plan["w"] % 16 != 0) | (plan["c"] % 8 != 0) | (plan["bias"] % 8 != 0) |
+           (plan["N"] % 128 != 0) | (plan["K"] % 128 != 0) | (plan["a_kseg"] % 64 != 0) | (plan["c_nseg"] % 16 != 0) |
+           ((plan["a_so"] | plan["a_si"] | plan["a_ss"]) % 8 != 0) | ((plan["c_so"] | plan["c_si"] | plan["c_ss"]) % 4 != 0))
+    if bad.any():
+        raise RuntimeError(f"encoder_pipe: projection problem {plan[bad][0]} is outside caiman_proj_gemm's geometry "
+                           "(_proj_ok admitted the widths; operand alignment / segment sizes do not fit)")
+    return plan, ranges
 
 
 def _proj_launch(lib, plan, rng, tag, st, tile):

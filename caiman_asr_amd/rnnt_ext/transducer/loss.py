@@ -22,16 +22,19 @@ _NO_EOS, _NO_STAR = -1, -2   # sentinels the kernels understand as "feature off"
 # whole gradient tensor (5.3 GB at B = 32).  The sums are left here for the projection's backward to pick up
 # (train_utils/overlap.py::_LinearTransposedBackward); nothing changes for a consumer that does not look.
 FUSE_BIAS_GRADIENT = True
-_latest_colsum = None   # (data_ptr, shape, dtype, column sums) of the most recent x_grad
+_latest_colsum = None   # (data_ptr, shape, dtype, version counter, column sums) of the most recent x_grad
 
 
 def take_bias_gradient(dy: torch.Tensor):
-    """Column sums of `dy` if `dy` IS the gradient tensor the last loss backward produced (same storage, shape, dtype),
-    else None."""
+    """Column sums of `dy` if `dy` IS the gradient tensor the last loss backward produced -- same storage, shape and
+    dtype, and NOT written since (its version counter has not moved: a tensor hook that rescales the logits' gradient
+    in place, or autograd accumulating a second consumer's gradient into it, would leave the sums stale) -- else None.
+    An entry is good for one backward pass: the next loss forward clears it."""
     global _latest_colsum
     ent, _latest_colsum = _latest_colsum, None
-    if ent is not None and ent[0] == dy.data_ptr() and ent[1] == tuple(dy.shape) and ent[2] == dy.dtype:
-        return ent[3]
+    if (ent is not None and ent[0] == dy.data_ptr() and ent[1] == tuple(dy.shape) and ent[2] == dy.dtype
+            and ent[3] == dy._version):
+        return ent[4]
     return None
 
 
@@ -120,6 +123,8 @@ class TransducerLossFunc(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, label, f_len, y_len, batch_offset, delay_penalty, max_f_len, blank_idx, eos_penalty, eos_idx,
                 star_penalty, star_idx, debug_list, packed_input):
+        global _latest_colsum
+        _latest_colsum = None   # an untaken entry of an earlier pass must not meet a recycled allocation
         eos, star = _special_indices(blank_idx, eos_idx, star_idx)
         call = _LossCall(float(delay_penalty), int(max_f_len), int(blank_idx), float(eos_penalty), eos,
                          float(star_penalty), star, bool(packed_input))
@@ -145,7 +150,7 @@ class TransducerLossFunc(torch.autograd.Function):
         if FUSE_BIAS_GRADIENT and transducer_loss_cu.colsum_supported(x):
             x_grad, colsum = transducer_loss_cu.backward_colsum(x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len,
                                                                 label, batch_offset, *ctx.call.kernel_args())
-            _latest_colsum = (x_grad.data_ptr(), tuple(x_grad.shape), x_grad.dtype, colsum)
+            _latest_colsum = (x_grad.data_ptr(), tuple(x_grad.shape), x_grad.dtype, x_grad._version, colsum)
         else:
             x_grad = transducer_loss_cu.backward(x, denom, loss_grad.contiguous(), alpha, beta, f_len, y_len, label,
                                                  batch_offset, *ctx.call.kernel_args())

@@ -56,8 +56,13 @@ def train_step_batch_split(model, loss_fn, args: Namespace, feats, feat_lens, tx
                 loss.backward()
         loss_item += loss.item()
     reducer = getattr(m, "grad_reducer", None)
-    with sync_context(model, final_backward):
-        if reducer is not None and final_backward:
+    # A NaN slice drops the whole global batch (train.py:279-284; `batch_has_nan` is agreed across ranks by
+    # is_loss_nan's all-reduce): its gradients must not be handed to the reducer, whose finish() will not be called for
+    # this window -- the encoder / prediction backward below then only accumulates into an arena that the next window
+    # zeroes.
+    send = final_backward and not batch_has_nan
+    with sync_context(model, send):
+        if reducer is not None and send:
             reducer.mark_ready(m.joint_net.parameters())
         f.backward(f_2.grad)
         g.backward(g_2.grad)

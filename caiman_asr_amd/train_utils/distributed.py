@@ -38,9 +38,15 @@ from caiman_asr_amd.train_utils import overlap as _hooks
 
 class FlatGradReducer:
     def __init__(self, params: List[torch.nn.Parameter], offsets: List[int], flat_grad: torch.Tensor,
-                 process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True, measure_exposed: bool = False):
+                 process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True, measure_exposed: bool = False,
+                 force_distributed: bool = False):
+        """`force_distributed`: run the whole exchange (hooks, buckets, collectives, fences) even in a world of ONE rank,
+        where a mean all-reduce is the identity -- the only way to execute the RCCL code path on a one-GPU box
+        (tests/test_gpu_distributed.py); a normal run leaves it off and a world of one does nothing."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_distributed and dist.is_initialized())
+        self.launched_total = 0      # collectives launched since construction (tests, bench record)
         self.flat = flat_grad
         self.overlap = overlap and flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
@@ -75,7 +81,7 @@ class FlatGradReducer:
         self._stream_ordered = bool(dist.is_initialized() and self.overlap and dist.get_backend(process_group) == "nccl")
         self._guard = None       # (gradient element, failure count seen by the optimiser): see guard_handoffs()
         self._guard_bucket = None
-        if self.world > 1:
+        if self.active:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             # gradients that LSTM stacks add straight into `.grad` bypass autograd's accumulation: they report here
@@ -120,7 +126,7 @@ class FlatGradReducer:
 
     def _on_grad(self, p):
         """post-accumulate-grad hook / notification from a layer pipeline: always inside a backward pass."""
-        if self.world > 1 and not self._pass_cb_queued:
+        if self.active and not self._pass_cb_queued:
             self._pass_cb_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
         if self._syncing:
@@ -128,7 +134,7 @@ class FlatGradReducer:
 
     def _mark(self, p):
         b = self.param_bucket.get(id(p))
-        if b is None or self.world == 1:
+        if b is None or not self.active:
             return
         seen = self._ready[b].get(id(p))
         if seen is not None:
@@ -143,9 +149,10 @@ class FlatGradReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if self._launched[b] or self.world == 1:
+        if self._launched[b] or not self.active:
             return
         self._launched[b] = True
+        self.launched_total += 1
         s, e, _ = self.buckets[b]
         chunk = self.flat[s:e]
         if self.overlap:
@@ -167,7 +174,7 @@ class FlatGradReducer:
         """Launch whatever was not triggered by hooks (frozen / unused parameters, parameters last touched inside
         no_sync()), wait for all collectives and turn the sums into means.  Call after the last backward pass of
         the optimiser step, before optimizer.step()."""
-        if self.world > 1:
+        if self.active:
             if self._guard is not None and self.flat.is_cuda:
                 from caiman_asr_amd import _lib
 
@@ -187,12 +194,31 @@ class FlatGradReducer:
                     self._exposed_events.append((e0, e1))
                 else:
                     cur.wait_stream(self.comm_stream)
-            if average:
+            if average and self.world > 1:
                 self.flat.mul_(1.0 / self.world)
+        self._clear_step_state()
+
+    def _clear_step_state(self):
         self._handles = []
         for r in self._ready:
             r.clear()
         self._launched = [False] * len(self.buckets)
+        # the end-of-pass callback of a backward pass that raised never runs: do not let a stale "queued" flag stop the
+        # pass counter (and with it the accumulated-into-an-in-flight-bucket check) for the rest of the run
+        if self._pass_cb_queued:
+            self._pass_cb_queued = False
+            self._pass += 1
+
+    def reset(self):
+        """Abandon the current optimiser step (a NaN loss dropped the accumulation window, a backward pass raised):
+        wait for every collective already in flight -- the gradient arena they write is about to be zeroed -- and
+        forget which gradients were final.  The sums they produced are discarded with the window."""
+        if self.active:
+            for h in self._handles:
+                h.wait()
+            if self.overlap:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._clear_step_state()
 
     def exposed_ms(self, reset: bool = True) -> float:
         """Total time the compute stream waited for the collectives in finish() since the last reset (synchronises)."""

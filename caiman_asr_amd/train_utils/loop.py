@@ -57,6 +57,8 @@ class TrainStepper:
                                                   final_backward=final)
         if loss_nan:
             self.accumulated = 0   # NaNs pollute the accumulated gradients: the window restarts with zero_grad
+            if hasattr(self.opt, "drop_window"):
+                self.opt.drop_window()   # data parallel: nothing of the dropped window stays marked / in flight
         else:
             self.losses.append(loss_item)
             self.accumulated += 1

@@ -190,9 +190,21 @@ class OptimizerWrapper:
         self.args, self.optimizer, self.scaler, self.lower_bound = args, optimizer, scaler, lower_bound
         self.reducer = reducer
         self.scale = None   # override handed to the next scaler.update()
+        # a hand-off timeout drops the step on the device of the rank that saw it (caiman_lamb_step); the other ranks
+        # only drop it too when the reducer carries the poison (distributed.py::guard_handoffs): pairing a reducer with
+        # an optimiser therefore always arms the guard, otherwise the parameters would silently diverge across ranks
+        if reducer is not None and hasattr(optimizer, "_work") and getattr(reducer, "_guard", None) is None:
+            reducer.guard_handoffs(optimizer)
 
     def zero_grad(self) -> None:
         self.optimizer.zero_grad()
+
+    def drop_window(self) -> None:
+        """A NaN loss dropped the accumulation window (train.py:279-284): nothing of it may reach optimizer.step().
+        Under data parallelism the reducer may hold marks (or, after a misuse, collectives in flight) of the dropped
+        window: they are drained and forgotten before the next window's zero_grad touches the gradient arena."""
+        if self.reducer is not None:
+            self.reducer.reset()
 
     def step(self, total_norm: Optional[float] = None) -> None:
         """`total_norm` is accepted for signature parity; the finite test runs on the device."""

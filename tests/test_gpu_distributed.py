@@ -107,6 +107,24 @@ def _worker(rank, world, port, out):
             assert torch.equal(gathered[0], gathered[1])
             report[tag] = (worst, int(_lib.lib().caiman_lstm_resident_launches() - n_res))
 
+            # A NaN loss in the LAST micro-batch of a window under batch splitting (one rank's slice only): every rank
+            # drops the window (train.py:279-284), nothing of it may be handed to the reducer, and the next window must
+            # run as if nothing had happened (round-2 advisor finding: the final backward used to launch the buckets,
+            # finish() was never called, and the next final backward raised "bucket already in flight").
+            steps_before = int(opt._step.item())
+            assert stepper.micro_batch(*_batch(g, mine[:2])) is None
+            xb = list(_batch(g, mine[2:]))
+            if rank == 1:
+                xb[0] = torch.full_like(xb[0], float("nan"))
+            assert stepper.micro_batch(*xb) is None, "a NaN window must not reach the optimiser"
+            assert stepper.accumulated == 0 and not any(red._launched) and not any(red._ready)
+            captured.clear()
+            assert stepper.micro_batch(*_batch(g, mine[:2])) is None
+            assert stepper.micro_batch(*_batch(g, mine[2:])) is not None
+            torch.cuda.synchronize()
+            assert int(opt._step.item()) == steps_before + 1
+            assert all(torch.isfinite(v).all() for v in captured.values())
+
             # a hand-off timeout on ONE rank makes EVERY rank drop the step (guard_handoffs + caiman_lstm_resident_poison)
             if tag == "mfma":
                 before = opt.flat_p.clone()
@@ -147,3 +165,120 @@ def test_two_ranks_real_model_batch_split_and_accumulation_match_single_process(
     # the bf16 model ran its encoder through the layer pipeline (weight-resident launches) on both ranks
     for rank, _, payload in res:
         assert payload["mfma"][1] > 0, payload
+
+
+def _nccl_world1_worker(port, out):
+    """The RCCL code path on the one GPU there is: a world-size-1 `nccl` process group, the reducer told to behave as if
+    distributed, one real train step through encoder_pipe.  (The reference: NCCL DDP,
+    training/caiman_asr_train/setup/train.py:190-196, setup/base.py:497-501.)"""
+    import time
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from caiman_asr_amd import _lib
+        from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers
+        from caiman_asr_amd.train_utils import overlap
+        from caiman_asr_amd.train_utils.core import train_step
+        from caiman_asr_amd.train_utils.distributed import FlatGradReducer, broadcast_parameters
+        from caiman_asr_amd.train_utils.optimizer import OptimizerWrapper, build_optimizer
+
+        lib = _lib.lib()
+        warm = torch.ones(1024, device="cuda")
+        dist.all_reduce(warm)              # communicator set-up happens here, not inside the timed part below
+        torch.cuda.synchronize()
+
+        g, ref_model = _build("mfma")
+        V = int(g["n_classes"])
+        loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+        mods = LossModifiers(delay_penalty=0.01, eos_penalty=0.0, star_penalty=1.0)
+        a1 = Namespace(grad_accumulation_batches=1, batch_split_factor=1, no_amp=False, num_gpus=1)
+        batch = _batch(g, GLOBAL_IDX)
+        loss_ref, nan, _ = train_step(ref_model, loss_fn, a1, *batch, None, None, mods)
+        assert not nan
+        ref = {n: p.grad.clone() for n, p in ref_model.named_parameters()}
+
+        g, m = _build("mfma")
+        assert m.encoder_pipe
+        opt = build_optimizer(Namespace(lr=4e-3, weight_decay=1e-2, beta1=0.9, beta2=0.999, clip_norm=1.0, ema=0.999), m)
+        broadcast_parameters(opt.flat_p)
+        red = FlatGradReducer(opt._params, opt._offsets, opt.flat_g, bucket_bytes=16 << 10, force_distributed=True,
+                              measure_exposed=True).attach(m)
+        wrapper = OptimizerWrapper(a1, opt, reducer=red)
+        assert red.active and red.world == 1
+        assert red._stream_ordered, "the nccl backend must take the stream-ordered branch (h.wait() on the side stream)"
+        assert red._guard is not None, "pairing a reducer with an optimiser arms the hand-off guard"
+        assert len(red.buckets) >= 3
+
+        # (1) the real step: hooks launch the buckets on the side stream during backward, finish() joins them
+        n_res = lib.caiman_lstm_resident_launches()
+        loss, nan, _ = train_step(m, loss_fn, a1, *batch, None, None, mods)
+        assert not nan and red.launched_total >= 1     # hooks launched buckets during the backward pass
+        red.finish()
+        torch.cuda.synchronize()
+        assert red.launched_total == len(red.buckets)
+        assert lib.caiman_lstm_resident_launches() > n_res, "encoder_pipe ran no weight-resident launch"
+        assert lib.caiman_lstm_resident_failures() == 0
+        assert abs(loss - loss_ref) <= 1e-6 * abs(loss_ref)
+        worst = 0.0
+        for n, p in m.named_parameters():
+            err = (p.grad - ref[n]).abs().max().item() / (ref[n].abs().max().item() + 1e-12)
+            worst = max(worst, err)
+            assert err <= 1e-6, (n, err)      # a mean over one rank is the identity
+        wrapper.optimizer.step()
+        torch.cuda.synchronize()
+        assert opt.last_step_applied.item() == 1
+
+        # (2) h.wait() inside the side-stream context is a STREAM wait: with ~100 ms of work queued in front of the
+        # collectives the host gets through every launch long before the device does
+        opt.zero_grad()
+        a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        for _ in range(150):
+            a @ a
+        t0 = time.perf_counter()
+        red.mark_ready(opt._params)            # every bucket but the guarded one is launched from here
+        host_s = time.perf_counter() - t0
+        pending = not red.comm_stream.query()
+        # (3) fence_collectives(): whatever the main stream runs next (a weight-resident LSTM launch in the stacks) is
+        # ordered behind the collectives queued so far
+        e_coll = torch.cuda.Event(enable_timing=True)
+        e_coll.record(red.comm_stream)
+        overlap.fence_collectives()
+        e_main = torch.cuda.Event(enable_timing=True)
+        e_main.record(torch.cuda.current_stream())
+        e_main.synchronize()
+        fenced = e_coll.query()                # the main stream got past the fence only after the side stream's work
+        order_ms = e_coll.elapsed_time(e_main)
+        red.finish()
+        torch.cuda.synchronize()
+        assert host_s < 0.05, f"launching the collectives blocked the host for {host_s * 1e3:.1f} ms"
+        assert pending, "the side stream was already idle: the non-blocking check did not see queued work"
+        assert fenced and order_ms >= 0.0, (fenced, order_ms)
+        red.remove()
+        out.put(("ok", {"worst_grad_err": worst, "host_launch_ms": host_s * 1e3, "buckets": len(red.buckets),
+                        "backend": dist.get_backend()}))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        out.put(("fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_path_runs_in_a_world_of_one_on_the_real_model():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), out))
+    p.start()
+    status, payload = out.get(timeout=540)
+    p.join(timeout=60)
+    assert status == "ok", payload
+    assert payload["backend"] == "nccl"

@@ -75,7 +75,9 @@ def _resident_fwd_bwd(R, gates_ref, c0, y0, delta, hard, expect_resident=True):
 
 @pytest.mark.parametrize("T,B,H", [(40, 32, 128), (40, 32, 1024), (33, 7, 256), (24, 32, 768),
                                    # batch tiles of 32 rows (lstm_fwd_resident_bt / lstm_bwd_resident2_bt): ragged, 2 and 4 tiles
-                                   (12, 33, 512), (10, 64, 1024), (6, 128, 1024), (10, 100, 512)])
+                                   (12, 33, 512), (10, 64, 1024), (6, 128, 1024), (10, 100, 512),
+                                   # H = 1536 (large-196M encoder): DMA-gather forward kernel, 2-D split backward with 3 stages
+                                   (20, 32, 1536), (17, 7, 1536)])
 @pytest.mark.parametrize("hard", [False, True])
 def test_resident_kernels_match_the_f64_oracle(T, B, H, hard):
     from oracle import native
@@ -108,6 +110,65 @@ def test_resident_kernels_match_the_f64_oracle(T, B, H, hard):
     check("dG", dG, odG, 24, 1.5)
     ob = odG.sum((0, 1))
     assert np.allclose(dbias.double().numpy(), ob, atol=3e-2 * max(1.0, np.abs(ob).max())), "fused bias gradient"
+
+
+def test_wide_layers_go_out_in_chip_sized_slot_groups():
+    """H = 1536: a layer takes 48 workgroups, so a pipeline tick of 7 layers does not fit the 256 CUs as one resident grid;
+    the wave calls split the slots into consecutive launches (5 + 2).  Every slot must equal the same layer run alone,
+    bit for bit, and the launch count must show the split."""
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    T, B, H, n = 6, 8, 1536, 7
+    dt = torch.bfloat16
+    tag, st = _lib.dtype_tag(dt), _lib.stream()
+    g = torch.Generator().manual_seed(77)
+    bp = 32
+    per_launch = 256 // 48
+    R = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt).to(DEV) for _ in range(n)]
+    G0 = [torch.randn(T, B, 4 * H, generator=g).to(dt).to(DEV) for _ in range(n)]
+    D = [torch.randn(T, B, H, generator=g).to(dt).to(DEV) for _ in range(n)]
+
+    def run(group):
+        """forward + backward of the layers in `group` in one wave call each way -> per layer (G, Y, dG, dbias)"""
+        k = len(group)
+        G = [G0[i].clone() for i in group]
+        C = [torch.zeros(T + 1, B, H, dtype=dt, device=DEV) for _ in group]
+        Y = [torch.zeros(T + 1, B, H, dtype=dt, device=DEV) for _ in group]
+        wt = [torch.empty(4 * H * H, dtype=dt, device=DEV) for _ in group]
+        ring = [torch.zeros(2 * bp * H, dtype=dt, device=DEV) for _ in group]
+        for j, i in enumerate(group):
+            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(R[i]), _lib.ptr(Y[j][0]), _lib.ptr(wt[j]), _lib.ptr(ring[j]), None, B, H, tag, 0, 1, st))
+        arr = (_lib.FwdSlot * k)(*[_lib.FwdSlot(wt[j].data_ptr(), G[j].data_ptr(), C[j].data_ptr(), Y[j].data_ptr(), ring[j].data_ptr(),
+                                                0, T, None, 0, 0.0, 0) for j in range(k)])
+        n0 = lib.caiman_lstm_resident_launches()
+        _lib.check(lib.caiman_lstm_wave_fwd(ctypes.cast(arr, ctypes.c_void_p), k, T, B, H, tag, 0, 1, 0, st))
+        dG = [torch.empty_like(G[j]) for j in range(k)]
+        wtb = [torch.empty(4 * H * H, dtype=dt, device=DEV) for _ in group]
+        ringb = [torch.zeros(2 * bp * 4 * H, dtype=dt, device=DEV) for _ in group]
+        dC = [torch.zeros(B * H, dtype=torch.float32, device=DEV) for _ in group]
+        db = [torch.zeros(4 * H, dtype=torch.float32, device=DEV) for _ in group]
+        for j, i in enumerate(group):
+            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(R[i]), None, _lib.ptr(wtb[j]), _lib.ptr(ringb[j]), _lib.ptr(dC[j]), B, H, tag, 1, 1, st))
+        thi = T - 1
+        barr = (_lib.BwdSlot * k)(*[_lib.BwdSlot(wtb[j].data_ptr(), G[j][thi].data_ptr(), C[j][thi].data_ptr(), D[i][thi].data_ptr(),
+                                                 D[i].stride(0), D[i].stride(1), dG[j][thi].data_ptr(), ringb[j].data_ptr(),
+                                                 dC[j].data_ptr(), thi & 1, T, 0, 0.0, 0, 0, 0, db[j].data_ptr())
+                                    for j, i in enumerate(group)])
+        _lib.check(lib.caiman_lstm_wave_bwd(ctypes.cast(barr, ctypes.c_void_p), k, T, B, H, tag, 0, 1, 0, st))
+        torch.cuda.synchronize()
+        assert lib.caiman_lstm_resident_failures() == 0
+        return [(G[j], Y[j], dG[j], db[j]) for j in range(k)], lib.caiman_lstm_resident_launches() - n0
+
+    together, launches = run(list(range(n)))
+    groups = (n + per_launch - 1) // per_launch
+    assert launches == 2 * groups, launches       # forward + backward, each split into `groups` resident launches
+    for i in range(n):
+        alone, one = run([i])
+        assert one == 2
+        for name, a, b in zip(("gates", "y", "dG", "dbias"), together[i], alone[0]):
+            assert torch.equal(a, b), (i, name)
+    assert not torch.equal(together[0][1], together[1][1])   # the slots are different layers
 
 
 def test_resident_geometry_guard_keeps_other_shapes_on_the_step_kernels():
