@@ -180,6 +180,7 @@ _SIGS = {
     "caiman_beam_topk": ([P, I64, I64, I64, I32, F32, I32, I32, I32, F32, F32, I32, P, P, P, P], ctypes.c_int),
     "caiman_beam_gather_inputs": ([P, I64, P, I64, P, P, I64, P, I64, I32, P], ctypes.c_int),
     "caiman_beam_lstm_cell": ([P, I64, P, P, P, P, P, I64, P, I64, I32, P], ctypes.c_int),
+    "caiman_lstm_step_gemm": ([P, I64, P, P, I64, I64, I64, P, P, P, P, P, P, I64, I32, P], ctypes.c_int),
     "caiman_beam_joint_act": ([P, P, P, I64, I64, P, I32, P], ctypes.c_int),
     "caiman_beam_create": ([ctypes.POINTER(BeamConfig), I32, ctypes.POINTER(ctypes.c_char_p), I32,
                             ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), I32], ctypes.c_void_p),

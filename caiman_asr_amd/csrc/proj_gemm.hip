@@ -50,8 +50,25 @@ struct ProjBatch {
 // KS = 2: two groups of NW waves share the tile and split its K range in halves (the K loop of a workgroup is a serial
 // chain of ~1 us steps; for the backward problems, K = 4H with one tile per CU, the chain IS the launch time); the halves
 // meet in LDS -- group 1 parks its accumulators in its own stage buffers, group 0 adds them and runs the epilogue.
-template <typename T, int BM, int BN, int NS, int NW, int KS>
-__global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb) {
+// CELL: the product is one timestep of an LSTM layer for M rows (live streams / pending hypotheses of the streaming
+// decoders): A = [x_t | h_{t-1}] rows, W = [W_ih | W_hh] with its 4H rows ordered [unit][gate] -- the lane that ends up
+// with four consecutive columns of a row holds the i, f, g, o pre-activations of ONE unit, so the cell update, the scatter
+// of (c, h) into the state pools by slot index and the next layer's input row are the epilogue (training/lib/csrc/lstm.cu:
+// 85-135 pointwise after :259-271's GEMM; training/caiman_asr_train/rnnt/beam.py:564-612): the gate matrix never exists.
+template <typename T>
+struct CellArgs {
+  float* c_pool;            // this layer's cell pool [1 + slots][H], f32
+  T* h_pool;                // this layer's hidden pool [1 + slots][H]
+  const T* h_pool_next;     // next layer's hidden pool or NULL (last layer)
+  const int32_t* slot_in;   // [M]: pool row - 1 the old state is read from
+  const int32_t* slot_out;  // [M]: pool row - 1 the new state is written to
+  T* x_next;                // [M][ldx]: [ h | h_pool_next[slot_in] ]
+  int64_t ldx;
+  int H;
+};
+
+template <typename T, int BM, int BN, int NS, int NW, int KS, bool CELL = false>
+__global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb, CellArgs<T> cell) {
   using frag = typename pfrag<T>::type;
   constexpr int BK = 64;
   constexpr int WGM = NW / 2;                     // waves along M; two along N
@@ -238,8 +255,35 @@ __global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb
   }
 
   // epilogue: lane holds, per 16 x 16 block, row m = r16 of the activations and columns 4 * kq .. + 3 of the weights
-  T* __restrict__ Cp = static_cast<T*>(P.c);
   const T* __restrict__ bias = static_cast<const T*>(P.bias);
+  if constexpr (CELL) {
+    const int H = cell.H;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int m = m0 + wm * WM + b * 16 + r16;
+      if (m >= M) continue;
+      const int64_t rin = (int64_t)(cell.slot_in[m] + 1) * H, rout = (int64_t)(cell.slot_out[m] + 1) * H;
+      T* xn = cell.x_next + (int64_t)m * cell.ldx;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        const int n = n0 + wn * WN + a * 16 + kq * 4, j = n >> 2;   // columns n .. n+3 = gates i, f, g, o of unit j
+        using v4 = __attribute__((ext_vector_type(4))) T;
+        const v4 bv = *reinterpret_cast<const v4*>(bias + n);
+        const float zi = acc[a][b][0] + static_cast<float>(bv[0]), zf = acc[a][b][1] + static_cast<float>(bv[1]);
+        const float zg = acc[a][b][2] + static_cast<float>(bv[2]), zo = acc[a][b][3] + static_cast<float>(bv[3]);
+        const float gi = 1.f / (1.f + expf(-zi)), gf = 1.f / (1.f + expf(-zf));
+        const float gg = tanhf(zg), go = 1.f / (1.f + expf(-zo));
+        const float c = gi * gg + gf * cell.c_pool[rin + j];
+        const T h = static_cast<T>(go * tanhf(c));
+        cell.c_pool[rout + j] = c;
+        cell.h_pool[rout + j] = h;
+        xn[j] = h;
+        if (cell.h_pool_next) xn[H + j] = cell.h_pool_next[rin + j];
+      }
+    }
+    return;
+  }
+  T* __restrict__ Cp = static_cast<T*>(P.c);
   const int c_nseg = P.c_nseg;
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
@@ -279,8 +323,23 @@ int launch_proj(const caiman_proj_problem_t* problems, int n, hipStream_t s) {
   for (int i = n; i <= kProjMax; ++i) pb.tile_begin[i] = tiles;
   for (int i = n; i < kProjMax; ++i) { pb.p[i] = problems[0]; pb.tiles_n[i] = 1; }
   if (tiles == 0) return CAIMAN_OK;
-  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, NS, NW, KS>), dim3((unsigned)tiles), dim3(64 * NW * KS), 0, s, pb);
+  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, NS, NW, KS>), dim3((unsigned)tiles), dim3(64 * NW * KS), 0, s, pb, CellArgs<T>{});
   return check_launch("projection GEMM");
+}
+
+template <typename T>
+int launch_cell_gemm(const caiman_proj_problem_t& prob, const CellArgs<T>& cell, hipStream_t s) {
+  constexpr int BM = 128, BN = 128;
+  ProjBatch pb;
+  pb.n = 1;
+  pb.p[0] = prob;
+  pb.tile_begin[0] = 0;
+  pb.tiles_n[0] = prob.N / BN;
+  const int tiles = ((prob.M + BM - 1) / BM) * pb.tiles_n[0];
+  for (int i = 1; i <= kProjMax; ++i) pb.tile_begin[i] = tiles;
+  for (int i = 1; i < kProjMax; ++i) { pb.p[i] = prob; pb.tiles_n[i] = 1; }
+  hipLaunchKernelGGL((proj_gemm_kernel<T, BM, BN, 2, 8, 1, true>), dim3((unsigned)tiles), dim3(64 * 8), 0, s, pb, cell);
+  return check_launch("LSTM step GEMM");
 }
 
 }  // namespace
@@ -326,4 +385,36 @@ extern "C" int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n, in
        : tile == 4 ? launch_proj<f16_t, 256, 128, 2, 8>(problems, n, s)
        : tile == 5 ? launch_proj<f16_t, 128, 128, 2, 8>(problems, n, s)
        : tile == 8 ? launch_proj<f16_t, 128, 128, 2, 8, 2>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
+}
+
+// One timestep of one LSTM layer for n rows as ONE launch (CellArgs above).  X [n][ldx_in] holds [x_t | h_{t-1}] rows,
+// K = the used width (multiple of 128; zero-pad x and the matching columns of W), W [4 hidden][K] with rows ordered
+// [unit][gate], bias [4 hidden] in the same order.
+extern "C" int caiman_lstm_step_gemm(const void* X, int64_t ldx_in, const void* W, const void* bias, int64_t n, int64_t hidden,
+                                     int64_t K, float* c_pool_l, void* h_pool_l, const void* h_pool_next,
+                                     const int32_t* slot_in, const int32_t* slot_out, void* X_next, int64_t ldx, int dtype,
+                                     caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(dtype == CAIMAN_BF16 || dtype == CAIMAN_F16, "lstm_step_gemm: bf16 / f16 only");
+  CAIMAN_CHECK(n >= 0 && n <= 0x7fffffffLL && hidden >= 32 && hidden % 32 == 0 && K >= 128 && K % 128 == 0 && ldx_in >= K &&
+                   ldx_in % 8 == 0 && ldx >= (h_pool_next ? 2 * hidden : hidden) && 4 * hidden <= 0x7fffffffLL,
+               "lstm_step_gemm: bad extents (hidden %% 32, K %% 128, ldx_in %% 8)");
+  if (n == 0) return CAIMAN_OK;
+  CAIMAN_CHECK(X && W && bias && c_pool_l && h_pool_l && slot_in && slot_out && X_next, "lstm_step_gemm: null pointer");
+  auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+  CAIMAN_CHECK(al(X, 16) && al(W, 16) && al(bias, 8), "lstm_step_gemm: X / W 16-byte, bias 8-byte aligned");
+  caiman_proj_problem_t p{};
+  p.a = X; p.w = W; p.bias = bias; p.c = X_next;
+  p.M = (int32_t)n; p.N = (int32_t)(4 * hidden); p.K = (int32_t)K;
+  p.a_inner = (int32_t)n; p.a_kseg = (int32_t)K; p.c_inner = (int32_t)n; p.c_nseg = (int32_t)(4 * hidden);
+  p.a_stride_outer = 0; p.a_stride_inner = ldx_in; p.a_stride_seg = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == CAIMAN_BF16) {
+    CellArgs<bf16_t> c{c_pool_l, static_cast<bf16_t*>(h_pool_l), static_cast<const bf16_t*>(h_pool_next), slot_in, slot_out,
+                       static_cast<bf16_t*>(X_next), ldx, (int)hidden};
+    return launch_cell_gemm<bf16_t>(p, c, s);
+  }
+  CellArgs<f16_t> c{c_pool_l, static_cast<f16_t*>(h_pool_l), static_cast<const f16_t*>(h_pool_next), slot_in, slot_out,
+                    static_cast<f16_t*>(X_next), ldx, (int)hidden};
+  return launch_cell_gemm<f16_t>(p, c, s);
 }

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from caiman_asr_amd import _lib
+from caiman_asr_amd.rnnt import streaming_lstm
 from caiman_asr_amd.rnnt.decoder import RNNTCommonDecoder, StreamingEncoder
 from caiman_asr_amd.rnnt.eos_strategy import EOSBlank, EOSIgnore, EOSPredict
 from caiman_asr_amd.rnnt.response import DecodingResponse, FrameResponses, HypothesisResponse
@@ -218,7 +219,11 @@ class HipBeamStep:
                 w = dict(embed=m.prediction["embed"].weight.detach().to(cd).contiguous(),
                          Wp=m.joint_pred.weight.detach().to(cd).contiguous(), bp=m.joint_pred.bias.detach().to(cd),
                          Wf=m.joint_fc.weight.detach().to(cd).contiguous(), bf=m.joint_fc.bias.detach().to(cd))
+                w["fused"] = streaming_lstm.fused_step_ok(self.H, cd) and w["embed"].shape[1] % 128 == 0
                 for l in range(self.L):
+                    if w["fused"]:   # one launch per layer-step: GEMM with the cell update as its epilogue
+                        w[f"W{l}"], w[f"b{l}"], _ = streaming_lstm.fused_layer_weights(lstm, l, cd)
+                        continue
                     w[f"W{l}"] = torch.cat([getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}")], 1) \
                         .detach().to(cd).contiguous()
                     w[f"b{l}"] = (getattr(lstm, f"bias_ih_l{l}") + getattr(lstm, f"bias_hh_l{l}")).detach().to(cd)
@@ -278,8 +283,12 @@ class HipBeamStep:
         _lib.check(lib.caiman_beam_gather_inputs(_lib.ptr(w["embed"]), E, _lib.ptr(self.h_pool[0]), H, y, s_in, n,
                                                  _lib.ptr(self.X[0]), self.X[0].shape[1], tag, st))
         for l in range(L):
-            torch.addmm(w[f"b{l}"], self.X[l][:n], w[f"W{l}"].t(), out=self.gates[:n])
             nxt = self.X[l + 1] if l + 1 < L else self.G_in
+            if w["fused"]:
+                streaming_lstm.lstm_step_gemm(self.X[l], w[f"W{l}"], w[f"b{l}"], n, H, self.c_pool[l], self.h_pool[l],
+                                              self.h_pool[l + 1] if l + 1 < L else None, s_in, s_out, nxt, tag, st)
+                continue
+            torch.addmm(w[f"b{l}"], self.X[l][:n], w[f"W{l}"].t(), out=self.gates[:n])
             _lib.check(lib.caiman_beam_lstm_cell(_lib.ptr(self.gates), H, _lib.ptr(self.c_pool[l]), _lib.ptr(self.h_pool[l]),
                                                  _lib.ptr(self.h_pool[l + 1]) if l + 1 < L else None, s_in, s_out, n,
                                                  _lib.ptr(nxt), nxt.shape[1], tag, st))

@@ -6,11 +6,47 @@ is a well-shaped library GEMM, gates = [x_t | h_{t-1}] · [W_ih | W_hh]^T + (b_i
 kernel of the beam round (`caiman_beam_lstm_cell`, include/caiman_beam.h), which also writes the next layer's
 input row.  State lives in pools [layers, 1 + rows, hidden] (row 0 unused here), h in the compute dtype, c in f32,
 and is updated in place.  Same arithmetic as the module path (training/lib/csrc/lstm.cu:99-123, i,f,g,o order)."""
+import os
 from typing import Optional
 
 import torch
 
 from caiman_asr_amd import _lib
+
+# One launch per layer-step: the 4-gate GEMM on MFMA with the cell update, the state scatter and the next layer's input
+# row as its epilogue (csrc/proj_gemm.hip, caiman_lstm_step_gemm) instead of library GEMM + cell kernel.
+# CAIMAN_DECODE_FUSED_LSTM=0 restores the two-launch form (A/B, and the fallback for hidden sizes % 128 != 0).
+FUSED_STEP = os.environ.get("CAIMAN_DECODE_FUSED_LSTM", "1") != "0"
+
+
+def _pad128(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+def fused_step_ok(hidden: int, cd) -> bool:
+    return FUSED_STEP and hidden % 128 == 0 and cd in (torch.float16, torch.bfloat16)
+
+
+def fused_layer_weights(lstm, l: int, cd):
+    """-> (W [4H, Ip + H] with rows ordered [unit][gate] and the input part zero-padded to Ip = pad128(I), bias [4H] in
+    the same order, Ip): the operand images of caiman_lstm_step_gemm for layer l."""
+    W_ih, W_hh = getattr(lstm, f"weight_ih_l{l}").detach(), getattr(lstm, f"weight_hh_l{l}").detach()
+    H, I = W_hh.shape[1], W_ih.shape[1]
+    Ip = _pad128(I)
+    W = torch.zeros(4 * H, Ip + H, device=W_ih.device, dtype=torch.float32)
+    W[:, :I] = W_ih
+    W[:, Ip:] = W_hh
+    W = W.view(4, H, Ip + H).transpose(0, 1).reshape(4 * H, Ip + H).to(cd).contiguous()
+    b = (getattr(lstm, f"bias_ih_l{l}") + getattr(lstm, f"bias_hh_l{l}")).detach().float().view(4, H).t().reshape(4 * H)
+    return W, b.to(cd).contiguous(), Ip
+
+
+def lstm_step_gemm(X, W, b, n, H, c_pool_l, h_pool_l, h_pool_next, s_in, s_out, nxt, tag, st):
+    """X [>= n, K] rows [x | h_prev]; pools / slots / nxt as caiman_beam_lstm_cell (s_in / s_out: device pointers)."""
+    _lib.check(_lib.lib().caiman_lstm_step_gemm(_lib.ptr(X), X.shape[1], _lib.ptr(W), _lib.ptr(b), n, H, W.shape[1],
+                                                _lib.ptr(c_pool_l), _lib.ptr(h_pool_l),
+                                                None if h_pool_next is None else _lib.ptr(h_pool_next), s_in, s_out,
+                                                _lib.ptr(nxt), nxt.shape[1], tag, st))
 
 
 class LargeBatchLSTM:
@@ -25,6 +61,7 @@ class LargeBatchLSTM:
         self.I = self.lstm.weight_ih_l0.shape[1]
         self.w = {}
         self.h = self.c = None
+        self.Ip = _pad128(self.I)      # fused step: layer 0's input columns padded to the GEMM's K granularity
 
     def _weights(self, cd):
         w = self.w.get(cd)
@@ -32,6 +69,9 @@ class LargeBatchLSTM:
             w = {}
             with torch.no_grad():
                 for l in range(self.L):
+                    if fused_step_ok(self.H, cd):
+                        w[f"W{l}"], w[f"b{l}"], _ = fused_layer_weights(self.lstm, l, cd)
+                        continue
                     w[f"W{l}"] = torch.cat([getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}")], 1) \
                         .detach().to(cd).contiguous()
                     w[f"b{l}"] = (getattr(self.lstm, f"bias_ih_l{l}") + getattr(self.lstm, f"bias_hh_l{l}")).detach().to(cd)
@@ -46,9 +86,10 @@ class LargeBatchLSTM:
             if self.c is None:
                 self.c = torch.zeros(L, B + 1, H, device=dev, dtype=torch.float32)
             self.iota = torch.arange(B, device=dev, dtype=torch.int32)
-            self.X = [torch.empty(B, (self.I if l == 0 else H) + H, device=dev, dtype=cd) for l in range(L)]
+            I0 = self.Ip if fused_step_ok(H, cd) else self.I
+            self.X = [torch.empty(B, (I0 if l == 0 else H) + H, device=dev, dtype=cd) for l in range(L)]
             self.top = torch.empty(B, H, device=dev, dtype=cd)
-            self.gates = torch.empty(B, 4 * H, device=dev, dtype=cd)
+            self.gates = None if fused_step_ok(H, cd) else torch.empty(B, 4 * H, device=dev, dtype=cd)
 
     def set_state(self, h: Optional[torch.Tensor], c: Optional[torch.Tensor]):
         """(h, c) each [L, B, H] as the module path carries them, or None for zeros."""
@@ -68,7 +109,12 @@ class LargeBatchLSTM:
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else self.lstm.weight_hh_l0.dtype
         self._ensure(x.device, cd)
         w = self._weights(cd)
-        x = x.to(cd).contiguous()
+        fused = fused_step_ok(self.H, cd)
+        x = x.to(cd)
+        if fused and self.Ip != I:
+            x = torch.nn.functional.pad(x, (0, self.Ip - I))     # zero columns meet zero weight columns
+            I = self.Ip
+        x = x.contiguous()
         lib, tag, st, H, L = _lib.lib(), _lib.dtype_tag(cd), _lib.stream(), self.H, self.L
         iota = _lib.ptr(self.iota)
         out = torch.empty(T, B, H, device=x.device, dtype=cd)
@@ -77,9 +123,13 @@ class LargeBatchLSTM:
             _lib.check(lib.caiman_beam_gather_inputs(_lib.ptr(x[t]), I, _lib.ptr(self.h[0]), H, iota, iota, B,
                                                      _lib.ptr(self.X[0]), self.X[0].shape[1], tag, st))
             for l in range(L):
-                torch.addmm(w[f"b{l}"], self.X[l], w[f"W{l}"].t(), out=self.gates)
                 last = l + 1 == L
                 nxt = out[t] if last else self.X[l + 1]
+                if fused:
+                    lstm_step_gemm(self.X[l], w[f"W{l}"], w[f"b{l}"], B, H, self.c[l], self.h[l],
+                                   None if last else self.h[l + 1], iota, iota, nxt, tag, st)
+                    continue
+                torch.addmm(w[f"b{l}"], self.X[l], w[f"W{l}"].t(), out=self.gates)
                 _lib.check(lib.caiman_beam_lstm_cell(_lib.ptr(self.gates), H, _lib.ptr(self.c[l]), _lib.ptr(self.h[l]),
                                                      None if last else _lib.ptr(self.h[l + 1]), iota, iota, B, _lib.ptr(nxt),
                                                      H if last else self.X[l + 1].shape[1], tag, st))
@@ -107,7 +157,11 @@ class LargeBatchPredictor:
             with torch.no_grad():
                 w = dict(embed=m.prediction["embed"].weight.detach().to(cd).contiguous(),
                          Wp=m.joint_pred.weight.detach().to(cd).contiguous(), bp=m.joint_pred.bias.detach().to(cd))
+                E = w["embed"].shape[1]
                 for l in range(self.L):
+                    if fused_step_ok(self.H, cd) and E % 128 == 0:
+                        w[f"W{l}"], w[f"b{l}"], _ = fused_layer_weights(self.lstm, l, cd)
+                        continue
                     w[f"W{l}"] = torch.cat([getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}")], 1) \
                         .detach().to(cd).contiguous()
                     w[f"b{l}"] = (getattr(self.lstm, f"bias_ih_l{l}") + getattr(self.lstm, f"bias_hh_l{l}")).detach().to(cd)
@@ -146,10 +200,15 @@ class LargeBatchPredictor:
         E = w["embed"].shape[1]
         _lib.check(lib.caiman_beam_gather_inputs(_lib.ptr(w["embed"]), E, _lib.ptr(self.h[0]), H, _lib.ptr(y32),
                                                  _lib.ptr(s_in), B, _lib.ptr(self.X[0]), self.X[0].shape[1], tag, st))
+        fused = fused_step_ok(H, cd) and E % 128 == 0
         for l in range(L):
-            torch.addmm(w[f"b{l}"], self.X[l], w[f"W{l}"].t(), out=self.gates)
             last = l + 1 == L
             nxt = self.top if last else self.X[l + 1]
+            if fused:
+                lstm_step_gemm(self.X[l], w[f"W{l}"], w[f"b{l}"], B, H, self.c[l], self.h[l], None if last else self.h[l + 1],
+                               _lib.ptr(s_in), _lib.ptr(s_out), nxt, tag, st)
+                continue
+            torch.addmm(w[f"b{l}"], self.X[l], w[f"W{l}"].t(), out=self.gates)
             _lib.check(lib.caiman_beam_lstm_cell(_lib.ptr(self.gates), H, _lib.ptr(self.c[l]), _lib.ptr(self.h[l]),
                                                  None if last else _lib.ptr(self.h[l + 1]), _lib.ptr(s_in), _lib.ptr(s_out), B,
                                                  _lib.ptr(nxt), nxt.shape[1], tag, st))

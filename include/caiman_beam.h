@@ -72,6 +72,19 @@ int caiman_beam_lstm_cell(const void* gates, int64_t hidden, float* c_pool_l, vo
 int caiman_beam_joint_act(const void* f_rows, const int64_t* row, const void* g, int64_t n,
                           int64_t joint_dim, void* A, int dtype, caiman_stream_t stream);
 
+/* One timestep of one LSTM layer for n rows (live streams of the streaming encoder, pending hypotheses of a beam round)
+ * as ONE launch: the 4-gate GEMM [x_t | h_prev] · [W_ih | W_hh]^T on MFMA with the cell update, the scatter of (c, h)
+ * into the state pools and the next layer's input row as its epilogue -- replaces the library GEMM + caiman_beam_lstm_cell
+ * pair above, i.e. the reference's cuBLAS GEMM + pointwise kernel per step (training/lib/csrc/lstm.cu:259-271, :85-135)
+ * as the decoders drive it (training/caiman_asr_train/rnnt/beam.py:564-612, batched_greedy.py:59-166).
+ *   X      [n, ldx_in]  rows [x_t | h_prev], K = used width (K % 128 == 0: zero-pad x and the matching columns of W)
+ *   W      [4·hidden, K] rows ordered [unit][gate] (row 4u + q = gate q (i,f,g,o) of unit u), bias [4·hidden] likewise
+ *   pools, slots, X_next, ldx: as caiman_beam_lstm_cell.  bf16 / f16. */
+int caiman_lstm_step_gemm(const void* X, int64_t ldx_in, const void* W, const void* bias, int64_t n, int64_t hidden,
+                          int64_t K, float* c_pool_l, void* h_pool_l, const void* h_pool_next,
+                          const int32_t* slot_in, const int32_t* slot_out, void* X_next, int64_t ldx, int dtype,
+                          caiman_stream_t stream);
+
 /* Search parameters: constructor arguments of RNNTBeamDecoder (beam.py:115-137). Thresholds < 0 mean
  * "off" (infinite), as in the reference (:153-154,190-200). */
 typedef struct {

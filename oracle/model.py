@@ -13,24 +13,80 @@ import torch
 
 from oracle import native
 
+# ---- storage rounding ---------------------------------------------------------------------------------------------
+# The HIP path computes in fp32 but STORES activations, weights images and activation gradients in the autocast type
+# (bf16).  `storage=torch.bfloat16` makes this restatement round at the same points -- forward values where the HIP
+# path writes a 16-bit tensor (rf), gradients where its backward pass writes one (rb) -- while all arithmetic between
+# two storage points stays float64.  A comparison of the bf16 HIP run against THIS oracle then measures the kernels,
+# not the 8-bit mantissa pushed through ten LSTM layers (which a comparison against the unrounded oracle has to allow
+# for).  Rounding points (file:line of the HIP side): LSTM operand images + bias sum (csrc/lstm_images.hip), projection
+# output = pre-activations (proj_gemm.hip epilogue / torch.addmm out dtype), h and c rows (lstm.hip: `cv`, `yv` of the
+# cell update; c is rounded for the NEXT step, tanh(c) uses the unrounded value), dG = gradient of the pre-activations
+# (lstm.hip backward epilogue: vI..vO), delta = dX of a layer (proj_gemm / matmul out dtype), autocast linears
+# (joint_enc / joint_pred / joint_fc: weight, bias, output and output gradient), joint activations (joint.hip).  Kept
+# unrounded where the HIP path keeps fp32: dC and dh inside the recurrence, the loss lattice, parameter gradients.
+_STORAGE = None
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def rf(x):
+    """value as the HIP path stores it (gradient passes unchanged)"""
+    return x if _STORAGE is None else _RoundFwd.apply(x, _STORAGE)
+
+
+def rb(x):
+    """gradient as the HIP path stores it (value passes unchanged)"""
+    return x if _STORAGE is None else _RoundBwd.apply(x, _STORAGE)
+
+
+def rfb(x):
+    return rb(rf(x))
+
+
+def _linear(x, w, b):
+    """autocast nn.Linear: 16-bit weight, bias and output; 16-bit output gradient"""
+    return rfb(x @ rf(w).t() + rf(b))
+
 
 def _lstm_stack(sd, prefix, x, num_layers, state=None):
-    """Plain-python multi-layer LSTM (gate order i,f,g,o)."""
+    """Plain-python multi-layer LSTM (gate order i,f,g,o).  `x` arrives as the layer below stored
+    it; the gradient this stack returns for it is rounded (it is a dX GEMM's output)."""
     T, B, _ = x.shape
     hs, cs = [], []
     for l in range(num_layers):
-        W, R = sd[f"{prefix}.weight_ih_l{l}"], sd[f"{prefix}.weight_hh_l{l}"]
-        b = sd[f"{prefix}.bias_ih_l{l}"] + sd[f"{prefix}.bias_hh_l{l}"]
+        W, R = rf(sd[f"{prefix}.weight_ih_l{l}"]), rf(sd[f"{prefix}.weight_hh_l{l}"])
+        b = rf(sd[f"{prefix}.bias_ih_l{l}"] + sd[f"{prefix}.bias_hh_l{l}"])
         H = R.shape[1]
         h = x.new_zeros(B, H) if state is None else state[0][l]
         c = x.new_zeros(B, H) if state is None else state[1][l]
-        pre_all = x @ W.t() + b
+        pre_all = rf(rb(x) @ W.t() + b)
         outs = []
         for t in range(T):
-            pre = pre_all[t] + h @ R.t()
+            pre = rb(pre_all[t] + h @ R.t())          # its gradient is dG[t], a stored row
             i, f, g, o = pre.split(H, dim=1)
-            c = torch.sigmoid(i) * torch.tanh(g) + torch.sigmoid(f) * c
-            h = torch.sigmoid(o) * torch.tanh(c)
+            c_new = torch.sigmoid(i) * torch.tanh(g) + torch.sigmoid(f) * c
+            h = rf(torch.sigmoid(o) * torch.tanh(c_new))
+            c = rf(c_new)
             outs.append(h)
         x = torch.stack(outs, 0)
         hs.append(h)
@@ -49,23 +105,23 @@ def stack_time(x, lens, factor):
 
 
 def encode(sd, cfg, x, x_lens):
-    x, _ = _lstm_stack(sd, "encoder.pre_rnn.lstm", x, cfg["enc_pre_rnn_layers"])
+    x, _ = _lstm_stack(sd, "encoder.pre_rnn.lstm", rf(x), cfg["enc_pre_rnn_layers"])
     x, lens = stack_time(x, x_lens, cfg["enc_stack_time_factor"])
     x, _ = _lstm_stack(sd, "encoder.post_rnn.lstm", x, cfg["enc_post_rnn_layers"])
-    return x.transpose(0, 1) @ sd["joint_enc.weight"].t() + sd["joint_enc.bias"], lens
+    return _linear(rb(x).transpose(0, 1), sd["joint_enc.weight"], sd["joint_enc.bias"]), lens
 
 
 def predict(sd, cfg, y, state=None, add_sos=True):
     e = sd["prediction.embed.weight"][y]  # [B,U,H]
     if add_sos:
         e = torch.cat([e.new_zeros(e.shape[0], 1, e.shape[2]), e], 1)
-    g, st = _lstm_stack(sd, "prediction.dec_rnn.lstm", e.transpose(0, 1), cfg["pred_rnn_layers"], state)
-    return g.transpose(0, 1) @ sd["joint_pred.weight"].t() + sd["joint_pred.bias"], st
+    g, st = _lstm_stack(sd, "prediction.dec_rnn.lstm", rf(e).transpose(0, 1), cfg["pred_rnn_layers"], state)
+    return _linear(rb(g).transpose(0, 1), sd["joint_pred.weight"], sd["joint_pred.bias"]), st
 
 
 def joint(sd, f, g):
-    h = torch.relu(f.unsqueeze(2) + g.unsqueeze(1))
-    return h @ sd["joint_net.2.weight"].t() + sd["joint_net.2.bias"]
+    h = rfb(torch.relu(f.unsqueeze(2) + g.unsqueeze(1)))
+    return _linear(h, sd["joint_net.2.weight"], sd["joint_net.2.bias"])
 
 
 def forward(sd, cfg, x, x_lens, y, y_lens):
@@ -93,9 +149,20 @@ class OracleTransducerLoss(torch.autograd.Function):
 
 
 def loss_and_grads(sd_np, cfg, x, x_lens, y, y_lens, blank, delay_penalty=0.0, eos_penalty=0.0, eos_idx=None,
-                   star_penalty=1.0, star_idx=None, dtype=torch.float64):
-    """Batch-mean loss and d loss / d every parameter (dict name -> ndarray)."""
+                   star_penalty=1.0, star_idx=None, dtype=torch.float64, storage=None):
+    """Batch-mean loss and d loss / d every parameter (dict name -> ndarray).  `storage` (e.g. torch.bfloat16): round
+    stored activations / weight images / activation gradients where the HIP path stores them (top of this file)."""
+    global _STORAGE
     sd = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in sd_np.items()}
+    _STORAGE = storage
+    try:
+        return _loss_and_grads(sd, cfg, x, x_lens, y, y_lens, blank, delay_penalty, eos_penalty, eos_idx, star_penalty,
+                               star_idx, dtype)
+    finally:
+        _STORAGE = None
+
+
+def _loss_and_grads(sd, cfg, x, x_lens, y, y_lens, blank, delay_penalty, eos_penalty, eos_idx, star_penalty, star_idx, dtype):
     logits, f_lens = forward(sd, cfg, torch.as_tensor(x, dtype=dtype), torch.as_tensor(x_lens),
                              torch.as_tensor(y), torch.as_tensor(y_lens))
     mods = dict(delay_penalty=delay_penalty, eos_penalty=eos_penalty, eos_idx=eos_idx,

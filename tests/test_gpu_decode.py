@@ -300,3 +300,99 @@ def test_greedy_large_batch_predictor_equals_module_path(monkeypatch):
     assert tk0 == tk1 and ts0 == ts1 and sum(map(len, tk0)) > 10
     for a, b in zip(cf0, cf1):
         assert np.allclose(a, b, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,I,H,last", [(300, 240, 128, False), (2000, 512, 512, True), (129, 1024, 1024, False), (7, 128, 256, True)])
+def test_fused_lstm_step_gemm_matches_fp32_reference_and_the_two_launch_form(dtype, n, I, H, last):
+    """caiman_lstm_step_gemm (csrc/proj_gemm.hip, CELL epilogue): one timestep of one LSTM layer for n rows with state
+    pools addressed through slot indices, against (a) a plain fp32 torch evaluation of the same step
+    (training/lib/csrc/lstm.cu:99-123, gate order i,f,g,o) and (b) library GEMM + caiman_beam_lstm_cell, the form it
+    replaces.  Rows past a multiple of 128, a padded input width (I = 240 -> 256) and the last layer (no next pool)."""
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt import streaming_lstm as sl
+
+    torch.manual_seed(n + I + H)
+    lstm = torch.nn.LSTM(I, H, 1).to(DEV)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.mul_(2.0)
+    W, b, Ip = sl.fused_layer_weights(lstm, 0, dtype)
+    assert Ip % 128 == 0 and W.shape == (4 * H, Ip + H)
+    slots = 2 * n + 3
+    h_pool = (torch.randn(slots + 1, H, device=DEV) * 0.5).to(dtype)
+    c_pool = torch.randn(slots + 1, H, device=DEV) * 0.5
+    h_next = (torch.randn(slots + 1, H, device=DEV) * 0.5).to(dtype)
+    perm = torch.randperm(slots, device=DEV)
+    s_in = perm[:n].to(torch.int32).contiguous()
+    s_in[::5] = -1                                            # pool row 0: the zero start state
+    h_pool[0], c_pool[0] = 0, 0
+    s_out = perm[n:2 * n].to(torch.int32).contiguous()        # fresh slots, as the search hands them out
+    x = torch.randn(n, I, device=DEV).to(dtype)
+    X = torch.zeros(n, Ip + H, device=DEV, dtype=dtype)
+    X[:, :I] = x
+    X[:, Ip:] = h_pool[(s_in + 1).long()]
+    ldx = H if last else 2 * H
+    tag, st = _lib.dtype_tag(dtype), _lib.stream()
+
+    def run(fused):
+        hp, cp = h_pool.clone(), c_pool.clone()
+        nxt = torch.zeros(n, ldx, device=DEV, dtype=dtype)
+        if fused:
+            sl.lstm_step_gemm(X, W, b, n, H, cp, hp, None if last else h_next, _lib.ptr(s_in), _lib.ptr(s_out), nxt, tag, st)
+        else:
+            Wcat = torch.cat([lstm.weight_ih_l0, lstm.weight_hh_l0], 1).detach().to(dtype)
+            bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().to(dtype)
+            gates = torch.addmm(bias, torch.cat([x, X[:, Ip:]], 1), Wcat.t())
+            _lib.check(_lib.lib().caiman_beam_lstm_cell(_lib.ptr(gates), H, _lib.ptr(cp), _lib.ptr(hp),
+                                                        None if last else _lib.ptr(h_next), _lib.ptr(s_in), _lib.ptr(s_out), n,
+                                                        _lib.ptr(nxt), ldx, tag, st))
+        torch.cuda.synchronize()
+        return hp, cp, nxt
+
+    hp, cp, nxt = run(True)
+    # (a) fp32 reference from the SAME 16-bit operands
+    Wf = torch.cat([lstm.weight_ih_l0, lstm.weight_hh_l0], 1).detach().to(dtype).float()
+    bf = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().to(dtype).float()
+    z = torch.cat([x, X[:, Ip:]], 1).float() @ Wf.t() + bf
+    zi, zf, zg, zo = z.split(H, 1)
+    c_ref = torch.sigmoid(zi) * torch.tanh(zg) + torch.sigmoid(zf) * c_pool[(s_in + 1).long()]
+    h_ref = torch.sigmoid(zo) * torch.tanh(c_ref)
+    out_rows = (s_out + 1).long()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert torch.allclose(cp[out_rows], c_ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(hp[out_rows].float(), h_ref, atol=eps, rtol=eps)
+    assert torch.equal(nxt[:, :H], hp[out_rows])
+    if not last:
+        assert torch.equal(nxt[:, H:], h_next[(s_in + 1).long()])
+    untouched = torch.ones(slots + 1, dtype=torch.bool, device=DEV)
+    untouched[out_rows] = False
+    assert torch.equal(hp[untouched], h_pool[untouched]) and torch.equal(cp[untouched], c_pool[untouched])
+    # (b) the two-launch form rounds the pre-activations to 16 bits before the cell: agreement to that resolution
+    hp2, cp2, nxt2 = run(False)
+    assert torch.allclose(cp, cp2, atol=16 * eps, rtol=16 * eps) and torch.allclose(hp.float(), hp2.float(), atol=16 * eps, rtol=0)
+
+
+def test_large_batch_streaming_with_the_fused_step_equals_the_two_launch_form(monkeypatch):
+    """Streaming encoder (LargeBatchLSTM) at a hidden size the fused step takes (the golden mini model's 64 is not):
+    frames with CAIMAN_DECODE_FUSED_LSTM on and off agree to the storage resolution, for odd chunk sizes."""
+    from caiman_asr_amd.rnnt import streaming_lstm as sl
+    from caiman_asr_amd.rnnt.rnn import rnn
+
+    torch.manual_seed(4)
+    stack = rnn(input_size=240, hidden_size=256, num_layers=3, batch_norm=False, rw_dropout=0.0, dropout=0.0,
+                tensor_name="pre_rnn", forget_gate_bias=1.0, custom_lstm=True, quantize=False, hidden_hidden_bias_scale=0.0,
+                weights_init_scale=1.0, gpu_unavailable=False).to(DEV)
+    T, B = 9, 300
+    x = torch.randn(T, B, 240, device=DEV)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(sl, "FUSED_STEP", fused)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lb = sl.LargeBatchLSTM(stack, B)
+            ys = [lb.forward(x[t0:t0 + n]) for t0, n in ((0, 2), (2, 3), (5, 4))]
+        assert (lb.gates is None) == fused
+        outs.append((torch.cat(ys, 0).float(), lb.state()[1].clone()))
+    (y1, c1), (y0, c0) = outs
+    assert y1.shape == (T, B, 256)
+    assert torch.allclose(y1, y0, atol=3e-2, rtol=0) and torch.allclose(c1, c0, atol=5e-2, rtol=0)

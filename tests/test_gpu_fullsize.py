@@ -153,3 +153,55 @@ def test_base_85m_step_at_128_utterances_per_gpu_runs_on_the_batch_tile_kernels(
     for n in names:
         scale = float(g0[n].abs().max()) + 1e-12
         assert float((g1[n] - g0[n]).abs().max()) <= 6e-2 * scale, n
+
+
+def test_base_85m_step_at_128_matches_the_bf16_storage_oracle():
+    """BASELINE.json configs[2] per-GPU shape against the ORACLE (not against another kernel of this library): base-85M,
+    B = 128, T = 40 frames, one bf16 training step on the weight-resident batch-tile kernels vs oracle.model.loss_and_grads
+    rounded where the HIP path stores 16-bit values (`storage=torch.bfloat16`): loss and four gradients, one per
+    sub-network, within 1e-2 of the tensor's range; the unrounded oracle as a loose second check."""
+    import json
+    import os
+
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, get_packing_meta_data
+    from caiman_asr_amd.rnnt.model import RNNT
+    from oracle import model as omodel
+
+    lib = _lib.lib()
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rnnt_cfg_base.json")))
+    cfg = dict(cfg, enc_dropout=0.0, pred_dropout=0.0, joint_dropout=0.0)
+    V, B, T1 = 8704, 128, 40
+    torch.manual_seed(5)
+    m = RNNT(n_classes=V, **cfg).to(DEV).train()
+    sd = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(2)
+    x_lens = rng.integers(24, T1 + 1, size=B)
+    x_lens[0] = T1
+    y_lens = rng.integers(1, 4, size=B)
+    x = rng.standard_normal((T1, B, 240)).astype(np.float32)
+    y = rng.integers(0, V - 1, size=(B, 3))
+    xd, yd = torch.tensor(x, device=DEV), torch.tensor(y, device=DEV)
+    xl, yl = torch.tensor(x_lens), torch.tensor(y_lens)
+    meta = get_packing_meta_data(xl, yl, 2, device=DEV)
+    loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
+    names = ("encoder.pre_rnn.lstm.weight_hh_l0", "encoder.post_rnn.lstm.weight_ih_l0", "prediction.dec_rnn.lstm.weight_hh_l1",
+             "joint_net.2.weight")
+    n0 = lib.caiman_lstm_resident_launches()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits, out_lens, _ = m(xd, xl.to(DEV), yd, yl.to(DEV), batch_offset=meta["batch_offset"],
+                                packed_batch=meta["packed_batch"])
+        loss = loss_fn(logits, out_lens, yd, yl.to(DEV), meta["batch_offset"], meta["max_f_len"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert lib.caiman_lstm_resident_launches() > n0 and lib.caiman_lstm_resident_failures() == 0
+    got = {n: p.grad.double().cpu().numpy() for n, p in m.named_parameters() if n in names}
+    del logits
+    torch.cuda.empty_cache()
+    for storage, loss_tol, grad_tol in ((torch.bfloat16, 2e-3, 1e-2), (None, 5e-3, 1e-1)):
+        o_loss, o_grads, _ = omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, V - 1, dtype=torch.float32, storage=storage)
+        assert abs(loss.item() - o_loss) <= loss_tol * abs(o_loss), (storage, loss.item(), o_loss)
+        for n in names:
+            r = o_grads[n]
+            err = np.abs(got[n] - r).max() / (np.abs(r).max() + 1e-12)
+            assert err <= grad_tol, (storage, n, err)

@@ -271,19 +271,26 @@ def test_base_85m_on_baseline_config0_matches_the_oracle(size, V):
     yd, yl = torch.tensor(y, device=DEV), torch.tensor(y_lens)
     meta = get_packing_meta_data(xl, yl, 2, device=DEV)
     loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
-    for amp, loss_tol, grad_tol in ((False, 1e-5, 2e-3), (True, 5e-3, 6e-2)):
+    # bf16: the oracle rounded where the HIP path stores 16-bit values (oracle/model.py `storage`) is the tight check
+    # (<= 1e-2 of a tensor's range: what is left are tie-breaks of the roundings and the fp32 summation orders); the
+    # unrounded oracle stays as the loose one (it differs from the rounded oracle by several percent itself)
+    st_loss, st_grads, _ = omodel.loss_and_grads(sd, cfg, x, x_lens, y, y_lens, V - 1, dtype=torch.float64,
+                                                 storage=torch.bfloat16)
+    for amp, checks in ((False, [(ref_loss, ref_grads, 1e-5, 2e-3)]),
+                        (True, [(st_loss, st_grads, 2e-3, 1e-2), (ref_loss, ref_grads, 5e-3, 1e-1)])):
         m.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             logits, out_lens, _ = m(xd, xl.to(DEV), yd, yl.to(DEV), batch_offset=meta["batch_offset"],
                                     packed_batch=meta["packed_batch"])
             loss = loss_fn(logits, out_lens, yd, yl.to(DEV), meta["batch_offset"], meta["max_f_len"])
         loss.backward()
-        assert abs(loss.item() - ref_loss) <= loss_tol * abs(ref_loss), (amp, loss.item(), ref_loss)
         got = dict(m.named_parameters())
-        for n in names:
-            r = ref_grads[n]
-            err = np.abs(got[n].grad.double().cpu().numpy() - r).max() / (np.abs(r).max() + 1e-12)
-            assert err <= grad_tol, (amp, n, err)
+        for o_loss, o_grads, loss_tol, grad_tol in checks:
+            assert abs(loss.item() - o_loss) <= loss_tol * abs(o_loss), (amp, loss_tol, loss.item(), o_loss)
+            for n in names:
+                r = o_grads[n]
+                err = np.abs(got[n].grad.double().cpu().numpy() - r).max() / (np.abs(r).max() + 1e-12)
+                assert err <= grad_tol, (amp, grad_tol, n, err)
 
 
 # ---- the reference's own oracle-free pins ---------------------------------------------------------------------------
