@@ -215,6 +215,66 @@ def decode_record(streams=2000, ticks=100):
             "wall_s_including_model_setup": time.perf_counter() - t0}
 
 
+def feed_beside_step(step, args, dev, first_index):
+    """The reference's DALI pipeline runs on the training GPU beside the step (training/caiman_asr_train/data/dali/
+    pipeline.py:359-470).  Here: the timed loop's own steps (same synthetic batches, so the two figures compare) run once
+    more while AudioBatchLoader decodes FLAC files on 8 host threads and runs the frontend kernels on its side stream; the
+    main stream takes one fed batch per step (waits for its `ready` event) and drops it.  -> record for the bench line."""
+    import shutil
+    import tempfile
+
+    from caiman_asr_amd import _lib
+    from caiman_asr_amd.data.frontend import LogMelFrontend
+    from caiman_asr_amd.data.loader import AudioBatchLoader
+    from caiman_asr_amd.data.sampler import SamplerUtt
+
+    lib = _lib.lib()
+    tmp = tempfile.mkdtemp(prefix="bench_feed_")
+    try:
+        clip = os.path.join(ROOT, "tests", "golden", "ref_clip.flac")    # the one real recording in the repo: 8.89 s
+        for i in range(64):
+            shutil.copy(clip, os.path.join(tmp, f"c{i}.flac"))
+        n_steps = args.steps
+        n_utts = args.batch * (n_steps + 6)
+        utts = [SamplerUtt(f"c{i % 64}.flac", i, 8.89) for i in range(n_utts)]
+        toks = {i: [1, 2, 3] for i in range(n_utts)}
+        loader = AudioBatchLoader(utts, toks, tmp, args.batch, LogMelFrontend(device=str(dev)), decode_threads=8, prefetch=3,
+                                  device=str(dev))
+
+        def timed(with_feed):
+            it = iter(loader) if with_feed else None
+            if it is not None:
+                next(it)                       # allocations + first launches of the frontend kernels
+            torch.cuda.synchronize()
+            fails0, in_flight, fed = lib.caiman_lstm_resident_failures(), [], 0
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                if len(in_flight) >= 2:
+                    in_flight.pop(0).synchronize()
+                if it is not None:
+                    feats, _, _, _ = next(it)  # the main stream now waits for this batch's frontend kernels
+                    fed += feats.shape[1]
+                step(first_index + i, first_index + i)
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream())
+                in_flight.append(done)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n_steps * 1e3
+            if it is not None:
+                it.close()
+            return ms, fed, lib.caiman_lstm_resident_failures() - fails0
+
+        alone, _, _ = timed(False)
+        beside, fed, timeouts = timed(True)
+        return {"ms_per_step_alone": alone, "ms_per_step_with_feed": beside, "slowdown": beside / alone - 1.0,
+                "utterances_fed_per_step": fed / n_steps, "fed_audio_seconds_per_step": fed * 8.89 / n_steps,
+                "handoff_timeouts_with_feed": int(timeouts), "decode_threads": 8,
+                "what": "same steps timed twice in this process, without and with AudioBatchLoader running beside them "
+                        "(FLAC decode on host threads, H2D, log-mel + splice kernels on a side stream, one batch taken per step)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,6 +292,9 @@ def main():
     ap.add_argument("--main-priority", type=int, default=0,
                     help="run the step on a stream of this priority (-1 = above the side streams; 0 = the default stream; measured: no effect)")
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
+    ap.add_argument("--feed", action="store_true",
+                    help="after the timed loop, time the same steps again WHILE the data feed (AudioBatchLoader: 8 FLAC decode "
+                         "threads, side-stream log-mel / normalise / splice kernels) produces one batch per step (N = 1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -513,6 +576,12 @@ def main():
         native = _lib.lib()
         out["lstm_resident"] = {"launches": int(native.caiman_lstm_resident_launches()),
                                 "handoff_timeouts": int(native.caiman_lstm_resident_failures())}   # must be 0
+        if world == 1 and args.feed:
+            try:
+                log("feed beside the step")
+                out["feed"] = feed_beside_step(step, args, dev, args.warmup)
+            except Exception as e:
+                out["feed"] = {"error": repr(e)}
         if world == 1 and not args.no_decode and args.model == "base":
             try:
                 log("decode record (child process)")

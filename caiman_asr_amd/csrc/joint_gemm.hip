@@ -1,0 +1,284 @@
+// The joint projection of the transducer as a hand-written MFMA GEMM with the log-sum-exp of every output row folded
+// into its epilogue (SURVEY section 8 rows a13 + a14).
+//
+// Reference: `self.joint_fc(h)` = torch.nn.Linear(joint_n_hid, n_classes) on the packed joint activations
+// (training/caiman_asr_train/rnnt/model.py:409-439), followed, inside the loss, by a log-sum-exp over every row of the
+// logits it produced (training/lib/csrc/logsumexp.cu:65-105; call site training/lib/src/rnnt_ext/transducer/loss.py).
+// At LibriSpeech shapes that is C[304 000, 8704] = A[304 000, 768] · W[8704, 768]^T: 4 TFLOP, a 5.3 GB bf16 result, and a
+// second full read of those 5.3 GB for the row normalisers.  Here:
+//
+//   C[m][n] = bf16( sum_k A[m][k] W[n][k] + bias[n] ),   both operands K-contiguous, fp32 accumulation
+//   pmax[m][p], psum[m][p] = max / sum exp(. - max) over the 64 columns p of row m AS STORED (rounded to 16 bits)
+//
+// so the normaliser of a row becomes a reduction over N / 64 partial pairs (lse_partials_kernel) instead of a pass over
+// the logits.
+//
+// Geometry: one workgroup of 8 waves (2 along M x 4 along N) per 256 x 256 tile, wave tile 128 x 64 = 32 MFMA blocks of
+// 16 x 16 (v_mfma_f32_16x16x32, 128 accumulator registers).  K is walked in steps of 32 through a RING OF FOUR LDS stages
+// (4 x (256 + 256) rows x 64 B = 128 KB): both operand tiles arrive by LDS-DMA (global_load_lds_dwordx4, no staging
+// registers), THREE stages are in flight while the fourth is multiplied, and a step costs one counted wait + one bare
+// barrier:   s_waitcnt vmcnt(8)  ->  s_barrier  ->  issue stage s + 3  ->  12 ds_read_b128 + 32 MFMA.
+// Behind the barrier every wave's share of stage s has landed (each waited for its own DMAs: all but the two youngest
+// stages') and every wave has finished reading stage s - 1, whose buffer the DMAs of stage s + 3 overwrite.  The four
+// buffers are separate LDS objects named statically (loop unrolled by four), so the compiler can tell the buffer being read
+// from the ones being filled and does not drain the DMAs in front of the LDS reads (csrc/proj_gemm.hip, three-stage path,
+// is the same idea with two stages in flight).
+// LDS image: a row of a stage is 32 K-values = 64 B = four 16-byte pieces; a DMA instruction writes 16 rows lane-linear,
+// and piece q of row r is FETCHED from position q ^ ((r >> 2) & 3) of the source row, so that the 16 rows x one piece of a
+// fragment read (ds_read_b128, 16 lanes at a time) fall on 16 different bank groups.
+// The MFMA is issued transposed (A operand = 16 rows of W, B operand = 16 rows of the activations): a lane ends up with
+// FOUR CONSECUTIVE COLUMNS of one output row -- 8-byte stores, and the row-wise max / sum of the epilogue needs two
+// shuffles (the four lanes that share a row) instead of a transpose.
+// Workgroups are dealt to tiles through the XCD remap of the guide (T1, bijective form): the eight XCDs each get a
+// contiguous run of tiles, M-tile major, so the 34 workgroups that share an activation panel share an L2.
+#include "common.h"
+
+namespace caiman {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <typename T>
+struct jfrag {
+  using type = __attribute__((ext_vector_type(8))) T;
+};
+__device__ __forceinline__ f32x4 jmfma(jfrag<bf16_t>::type a, jfrag<bf16_t>::type b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 jmfma(jfrag<f16_t>::type a, jfrag<f16_t>::type b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+constexpr int JBM = 256, JBN = 256, JBK = 32, JNW = 8;
+constexpr int JTM = 8, JTN = 4;   // 16 x 16 blocks of a wave tile: 128 rows, 64 columns
+
+template <typename T, bool LSE>
+__global__ __launch_bounds__(64 * JNW, 1) void joint_fc_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                                   const T* __restrict__ bias, T* __restrict__ C,
+                                                                   float* __restrict__ pmax, float* __restrict__ psum, int M,
+                                                                   int N, int K, int tiles_n) {
+  using frag = typename jfrag<T>::type;
+  __shared__ __attribute__((aligned(1024))) T sA0[JBM * JBK], sA1[JBM * JBK], sA2[JBM * JBK], sA3[JBM * JBK];
+  __shared__ __attribute__((aligned(1024))) T sW0[JBN * JBK], sW1[JBN * JBK], sW2[JBN * JBK], sW3[JBN * JBK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tile of this workgroup: XCD remap (blocks bid, bid + 8, ... share an XCD: give them consecutive tiles)
+  int t;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = (t / tiles_n) * JBM, n0 = (t % tiles_n) * JBN;
+
+  // per-lane DMA sources as 32-bit byte offsets from wave-uniform bases.  A stage holds 16 blocks of 16 rows per operand;
+  // wave w brings blocks w and w + 8; lane l of a block brings the piece that belongs at (row l >> 2, position l & 3).
+  unsigned a_off[2], w_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + JNW * i) * 16 + (lane >> 2);
+    const int q = (lane & 3) ^ ((row >> 2) & 3);
+    const int m = m0 + row < M ? row : M - 1 - m0;          // rows past M re-read the last row; never stored
+    a_off[i] = (unsigned)((m * K + q * 8) * (int)sizeof(T));
+    w_off[i] = (unsigned)((row * K + q * 8) * (int)sizeof(T));
+  }
+  const char* a_base = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
+  const char* w_base = reinterpret_cast<const char*>(W + (int64_t)n0 * K);
+
+  auto issue = [&](T* lA, T* lW, int k0) {
+    const char* ab = a_base + (int64_t)k0 * (int64_t)sizeof(T);
+    const char* wb = w_base + (int64_t)k0 * (int64_t)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(lA + (wave + JNW * i) * 16 * JBK), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(lW + (wave + JNW * i) * 16 * JBK), 16, 0, 0);
+  };
+
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, kq = lane >> 4;
+  f32x4 acc[JTN][JTM];
+#pragma unroll
+  for (int a = 0; a < JTN; ++a)
+#pragma unroll
+    for (int b = 0; b < JTM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a stage (the same for every stage): row * 32 + piece * 8 elements
+  int wfo[JTN], afo[JTM];
+#pragma unroll
+  for (int a = 0; a < JTN; ++a) {
+    const int row = wc * 64 + a * 16 + r16;
+    wfo[a] = row * JBK + ((kq ^ ((row >> 2) & 3)) * 8);
+  }
+#pragma unroll
+  for (int b = 0; b < JTM; ++b) {
+    const int row = wr * 128 + b * 16 + r16;
+    afo[b] = row * JBK + ((kq ^ ((row >> 2) & 3)) * 8);
+  }
+
+  auto compute = [&](const T* lA, const T* lW) {
+    frag wf[JTN], af[JTM];
+#pragma unroll
+    for (int a = 0; a < JTN; ++a) wf[a] = *reinterpret_cast<const frag*>(lW + wfo[a]);
+#pragma unroll
+    for (int b = 0; b < JTM; ++b) af[b] = *reinterpret_cast<const frag*>(lA + afo[b]);
+#pragma unroll
+    for (int b = 0; b < JTM; ++b)
+#pragma unroll
+      for (int a = 0; a < JTN; ++a) acc[a][b] = jmfma(wf[a], af[b], acc[a][b]);
+  };
+
+  // s_waitcnt through the builtin (the compiler's own wait-count bookkeeping sees it).  simm16 = vmcnt[3:0] | expcnt 7 << 4 |
+  // lgkmcnt 0 << 8: this wave's DMAs of the stage about to be read have landed, its LDS reads of the stage before returned.
+  auto steady = [&](const T* cA, const T* cW, T* nA, T* nW, int s) {
+    __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): stages s + 1, s + 2 may still fly
+    __builtin_amdgcn_s_barrier();
+    issue(nA, nW, (s + 3) * JBK);
+    __builtin_amdgcn_sched_barrier(0);     // keep the DMAs at the head of the step (left alone the scheduler sinks them behind the MFMAs)
+    compute(cA, cW);
+  };
+  const int nk = K / JBK;                 // K % 128 == 0: a multiple of four stages, at least four
+  issue(sA0, sW0, 0);
+  issue(sA1, sW1, JBK);
+  issue(sA2, sW2, 2 * JBK);
+  int s = 0;
+  for (; s + 4 <= nk - 3; s += 4) {       // no conditions inside: the wait counts stay exact across the loop
+    steady(sA0, sW0, sA3, sW3, s);
+    steady(sA1, sW1, sA0, sW0, s + 1);
+    steady(sA2, sW2, sA1, sW1, s + 2);
+    steady(sA3, sW3, sA2, sW2, s + 3);
+  }
+  steady(sA0, sW0, sA3, sW3, s);          // s = nk - 4: the last stage goes into buffer 3
+  __builtin_amdgcn_s_waitcnt(0x0078);     // stage nk - 3; nk - 2, nk - 1 in flight
+  __builtin_amdgcn_s_barrier();
+  compute(sA1, sW1);
+  __builtin_amdgcn_s_waitcnt(0x0074);     // vmcnt(4)
+  __builtin_amdgcn_s_barrier();
+  compute(sA2, sW2);
+  __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  compute(sA3, sW3);
+
+  // epilogue: lane holds, per 16 x 16 block, row m = r16 of the activations and columns 4 * kq .. + 3 of the weights
+  using v4 = __attribute__((ext_vector_type(4))) T;
+  const int NP = N / 64;
+  float bcol[JTN][4];
+#pragma unroll
+  for (int a = 0; a < JTN; ++a) {
+    const int n = n0 + wc * 64 + a * 16 + kq * 4;
+    if (bias) {
+      const v4 bv = *reinterpret_cast<const v4*>(bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bcol[a][j] = static_cast<float>(bv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bcol[a][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < JTM; ++b) {
+    const int m = m0 + wr * 128 + b * 16 + r16;
+    const bool live = m < M;
+    T* crow = C + (int64_t)m * N + n0 + wc * 64 + kq * 4;
+    float v[JTN][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < JTN; ++a) {
+      v4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = static_cast<T>(acc[a][b][j] + bcol[a][j]);
+        if constexpr (LSE) {
+          v[a][j] = static_cast<float>(o[j]);      // the normaliser is that of the STORED logits
+          mx = fmaxf(mx, v[a][j]);
+        }
+      }
+      if (live) *reinterpret_cast<v4*>(crow + a * 16) = o;
+    }
+    if constexpr (LSE) {
+      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      // v == mx counts as 1 without going through exp: a piece of -inf only (or +inf) has the sum 1 per maximal element, not
+      // exp(inf - inf) = NaN; a NaN element (fmaxf skips it) still makes the sum NaN, as torch.logsumexp would
+      float sm = 0.f;
+#pragma unroll
+      for (int a = 0; a < JTN; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += (v[a][j] == mx) ? 1.f : __expf(v[a][j] - mx);
+      sm += __shfl_xor(sm, 16, kWave);
+      sm += __shfl_xor(sm, 32, kWave);
+      if (live && kq == 0) {
+        const int64_t p = (int64_t)m * NP + (n0 >> 6) + wc;
+        pmax[p] = mx;
+        psum[p] = sm;
+      }
+    }
+  }
+}
+
+// row normaliser from the partial pairs: lse = M + log(sum_p psum_p * exp(pmax_p - M)), M = max_p pmax_p.  One wave per row.
+__global__ __launch_bounds__(256) void lse_partials_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                          float* __restrict__ lse, int64_t rows, int NP) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* pm = pmax + row * NP;
+  const float* ps = psum + row * NP;
+  float mx = -INFINITY;
+  for (int p = lane; p < NP; p += 64) mx = fmaxf(mx, pm[p]);
+  mx = wave_reduce(mx, [](float a, float b) { return fmaxf(a, b); });
+  float sm = 0.f;
+  for (int p = lane; p < NP; p += 64) {
+    const float m = pm[p];
+    sm += (m == mx) ? ps[p] : ps[p] * __expf(m - mx);     // m == mx: also the all -inf / +inf rows (sum >= 1, no inf - inf)
+  }
+  sm = wave_reduce(sm, [](float a, float b) { return a + b; });
+  if (lane == 0) lse[row] = mx + logf(sm);
+}
+
+template <typename T>
+int launch_joint_fc(const T* A, const T* W, const T* bias, T* C, float* lse, float* ws, int64_t M, int64_t N, int64_t K,
+                    hipStream_t s) {
+  const int tiles_n = (int)(N / JBN);
+  const int64_t tiles = (M + JBM - 1) / JBM * tiles_n;
+  const int NP = (int)(N / 64);
+  if (lse) {
+    float* pmax = ws;
+    float* psum = ws + M * NP;
+    hipLaunchKernelGGL((joint_fc_gemm_kernel<T, true>), dim3((unsigned)tiles), dim3(64 * JNW), 0, s, A, W, bias, C, pmax, psum,
+                       (int)M, (int)N, (int)K, tiles_n);
+    hipLaunchKernelGGL(lse_partials_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, pmax, psum, lse, M, NP);
+  } else {
+    hipLaunchKernelGGL((joint_fc_gemm_kernel<T, false>), dim3((unsigned)tiles), dim3(64 * JNW), 0, s, A, W, bias, C, nullptr,
+                       nullptr, (int)M, (int)N, (int)K, tiles_n);
+  }
+  return check_launch("joint projection GEMM");
+}
+
+}  // namespace
+}  // namespace caiman
+
+extern "C" int64_t caiman_joint_fc_workspace_elems(int64_t M, int64_t N) { return 2 * M * (N / 64); }
+
+extern "C" int caiman_joint_fc_supported(int64_t M, int64_t N, int64_t K, int dtype) {
+  return (dtype == CAIMAN_BF16 || dtype == CAIMAN_F16) && M >= 1 && N >= 256 && N % 256 == 0 && K >= 128 && K % 128 == 0 &&
+                 M * N < ((int64_t)1 << 40) && (M + 255) / 256 * (N / 256) < ((int64_t)1 << 31) && 256 * K * 2 < ((int64_t)1 << 31)
+             ? 1 : 0;
+}
+
+extern "C" int caiman_joint_fc_forward(const void* A, const void* W, const void* bias, void* C, float* lse, float* workspace,
+                                       int64_t M, int64_t N, int64_t K, int dtype, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(caiman_joint_fc_supported(M, N, K, dtype),
+               "joint_fc_forward: bf16 / f16, N %% 256 == 0, K %% 128 == 0 (got M %lld N %lld K %lld dtype %d)", (long long)M,
+               (long long)N, (long long)K, dtype);
+  CAIMAN_CHECK(A && W && C && (lse == nullptr || workspace != nullptr), "joint_fc_forward: null pointer");
+  auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+  CAIMAN_CHECK(al(A, 16) && al(W, 16) && al(C, 8) && (!bias || al(bias, 8)), "joint_fc_forward: operands 16-byte, C / bias 8-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == CAIMAN_BF16)
+    return launch_joint_fc<bf16_t>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, lse, workspace, M, N, K, s);
+  return launch_joint_fc<f16_t>((const f16_t*)A, (const f16_t*)W, (const f16_t*)bias, (f16_t*)C, lse, workspace, M, N, K, s);
+}

@@ -221,9 +221,8 @@ class HipBeamStep:
                          Wf=m.joint_fc.weight.detach().to(cd).contiguous(), bf=m.joint_fc.bias.detach().to(cd))
                 w["fused"] = streaming_lstm.fused_step_ok(self.H, cd) and w["embed"].shape[1] % 128 == 0
                 for l in range(self.L):
-                    if w["fused"]:   # one launch per layer-step: GEMM with the cell update as its epilogue
-                        w[f"W{l}"], w[f"b{l}"], _ = streaming_lstm.fused_layer_weights(lstm, l, cd)
-                        continue
+                    if w["fused"]:   # one launch per layer-step: GEMM with the cell update as its epilogue (rounds up to FUSED_MAX_ROWS)
+                        w[f"Wc{l}"], w[f"bc{l}"], _ = streaming_lstm.fused_layer_weights(lstm, l, cd)
                     w[f"W{l}"] = torch.cat([getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}")], 1) \
                         .detach().to(cd).contiguous()
                     w[f"b{l}"] = (getattr(lstm, f"bias_ih_l{l}") + getattr(lstm, f"bias_hh_l{l}")).detach().to(cd)
@@ -284,8 +283,8 @@ class HipBeamStep:
                                                  _lib.ptr(self.X[0]), self.X[0].shape[1], tag, st))
         for l in range(L):
             nxt = self.X[l + 1] if l + 1 < L else self.G_in
-            if w["fused"]:
-                streaming_lstm.lstm_step_gemm(self.X[l], w[f"W{l}"], w[f"b{l}"], n, H, self.c_pool[l], self.h_pool[l],
+            if w["fused"] and n <= streaming_lstm.FUSED_MAX_ROWS:
+                streaming_lstm.lstm_step_gemm(self.X[l], w[f"Wc{l}"], w[f"bc{l}"], n, H, self.c_pool[l], self.h_pool[l],
                                               self.h_pool[l + 1] if l + 1 < L else None, s_in, s_out, nxt, tag, st)
                 continue
             torch.addmm(w[f"b{l}"], self.X[l][:n], w[f"W{l}"].t(), out=self.gates[:n])

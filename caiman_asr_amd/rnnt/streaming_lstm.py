@@ -17,14 +17,18 @@ from caiman_asr_amd import _lib
 # row as its epilogue (csrc/proj_gemm.hip, caiman_lstm_step_gemm) instead of library GEMM + cell kernel.
 # CAIMAN_DECODE_FUSED_LSTM=0 restores the two-launch form (A/B, and the fallback for hidden sizes % 128 != 0).
 FUSED_STEP = os.environ.get("CAIMAN_DECODE_FUSED_LSTM", "1") != "0"
+# Measured on one box (bench_decode.py): 2 000 beam streams, tick p50 16.5 - 18.4 ms (two launches) -> 12.1 - 13.6 ms (fused:
+# a round is latency-bound, two launches fewer per layer); 16 000 greedy streams 12.8 -> 14.9 ms (at that many rows the
+# library's big-tile GEMM beats the 128 x 128 tiles of the fused kernel by more than the cell pass costs).  Hence a row limit.
+FUSED_MAX_ROWS = int(os.environ.get("CAIMAN_DECODE_FUSED_MAX_ROWS", "6000"))
 
 
 def _pad128(n: int) -> int:
     return (n + 127) // 128 * 128
 
 
-def fused_step_ok(hidden: int, cd) -> bool:
-    return FUSED_STEP and hidden % 128 == 0 and cd in (torch.float16, torch.bfloat16)
+def fused_step_ok(hidden: int, cd, n_rows: int = 0) -> bool:
+    return FUSED_STEP and hidden % 128 == 0 and cd in (torch.float16, torch.bfloat16) and n_rows <= FUSED_MAX_ROWS
 
 
 def fused_layer_weights(lstm, l: int, cd):
@@ -69,7 +73,7 @@ class LargeBatchLSTM:
             w = {}
             with torch.no_grad():
                 for l in range(self.L):
-                    if fused_step_ok(self.H, cd):
+                    if fused_step_ok(self.H, cd, self.B):
                         w[f"W{l}"], w[f"b{l}"], _ = fused_layer_weights(self.lstm, l, cd)
                         continue
                     w[f"W{l}"] = torch.cat([getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}")], 1) \
@@ -86,10 +90,10 @@ class LargeBatchLSTM:
             if self.c is None:
                 self.c = torch.zeros(L, B + 1, H, device=dev, dtype=torch.float32)
             self.iota = torch.arange(B, device=dev, dtype=torch.int32)
-            I0 = self.Ip if fused_step_ok(H, cd) else self.I
+            I0 = self.Ip if fused_step_ok(H, cd, B) else self.I
             self.X = [torch.empty(B, (I0 if l == 0 else H) + H, device=dev, dtype=cd) for l in range(L)]
             self.top = torch.empty(B, H, device=dev, dtype=cd)
-            self.gates = None if fused_step_ok(H, cd) else torch.empty(B, 4 * H, device=dev, dtype=cd)
+            self.gates = None if fused_step_ok(H, cd, B) else torch.empty(B, 4 * H, device=dev, dtype=cd)
 
     def set_state(self, h: Optional[torch.Tensor], c: Optional[torch.Tensor]):
         """(h, c) each [L, B, H] as the module path carries them, or None for zeros."""
@@ -109,7 +113,7 @@ class LargeBatchLSTM:
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else self.lstm.weight_hh_l0.dtype
         self._ensure(x.device, cd)
         w = self._weights(cd)
-        fused = fused_step_ok(self.H, cd)
+        fused = fused_step_ok(self.H, cd, B)
         x = x.to(cd)
         if fused and self.Ip != I:
             x = torch.nn.functional.pad(x, (0, self.Ip - I))     # zero columns meet zero weight columns
@@ -159,7 +163,7 @@ class LargeBatchPredictor:
                          Wp=m.joint_pred.weight.detach().to(cd).contiguous(), bp=m.joint_pred.bias.detach().to(cd))
                 E = w["embed"].shape[1]
                 for l in range(self.L):
-                    if fused_step_ok(self.H, cd) and E % 128 == 0:
+                    if fused_step_ok(self.H, cd, self.B) and E % 128 == 0:
                         w[f"W{l}"], w[f"b{l}"], _ = fused_layer_weights(self.lstm, l, cd)
                         continue
                     w[f"W{l}"] = torch.cat([getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}")], 1) \
@@ -200,7 +204,7 @@ class LargeBatchPredictor:
         E = w["embed"].shape[1]
         _lib.check(lib.caiman_beam_gather_inputs(_lib.ptr(w["embed"]), E, _lib.ptr(self.h[0]), H, _lib.ptr(y32),
                                                  _lib.ptr(s_in), B, _lib.ptr(self.X[0]), self.X[0].shape[1], tag, st))
-        fused = fused_step_ok(H, cd) and E % 128 == 0
+        fused = fused_step_ok(H, cd, B) and E % 128 == 0
         for l in range(L):
             last = l + 1 == L
             nxt = self.top if last else self.X[l + 1]

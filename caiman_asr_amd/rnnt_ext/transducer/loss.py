@@ -38,6 +38,28 @@ def take_bias_gradient(dy: torch.Tensor):
     return None
 
 
+# The projection that produced the logits may have computed their row normalisers already (csrc/joint_gemm.hip: log-sum-exp
+# in the GEMM epilogue, train_utils/overlap.py).  Same hand-over discipline as the bias gradient above: the entry names
+# the tensor by storage, shape, dtype and version counter, is good for ONE loss forward, and nothing changes for a caller
+# that never offers.
+_latest_row_lse = None
+
+
+def offer_row_lse(logits: torch.Tensor, lse: torch.Tensor):
+    global _latest_row_lse
+    _latest_row_lse = (logits.data_ptr(), tuple(logits.shape), logits.dtype, logits._version, lse)
+
+
+def take_row_lse(x: torch.Tensor):
+    """log-sum-exp of every row of `x` if the projection that wrote `x` left it here (and `x` was not written since)."""
+    global _latest_row_lse
+    ent, _latest_row_lse = _latest_row_lse, None
+    if (ent is not None and ent[0] == x.data_ptr() and ent[1] == tuple(x.shape) and ent[2] == x.dtype
+            and ent[3] == x._version and ent[4].numel() == x.numel() // x.shape[-1]):
+        return ent[4]
+    return None
+
+
 @dataclass(frozen=True)
 class _LossCall:
     """Scalars of one loss evaluation, in the units the kernels take them."""
@@ -134,7 +156,10 @@ class TransducerLossFunc(torch.autograd.Function):
             if not x.is_contiguous():
                 raise AssertionError("activations must be contiguous or packed")
             rows = x.view(-1, x.shape[-1])
-        denom = logsumexp_cu.logsumexp(rows, 128, True).view(x.shape[:-1])   # log-normaliser of every lattice cell
+        denom = take_row_lse(x)
+        if denom is None:
+            denom = logsumexp_cu.logsumexp(rows, 128, True)    # log-normaliser of every lattice cell
+        denom = denom.view(x.shape[:-1])
         alpha, beta, loss = transducer_loss_cu.forward(x, denom, label, f_len, y_len, batch_offset, *call.kernel_args())
         if debug_list is not None and len(debug_list) == 0:
             debug_list.extend((alpha, beta))

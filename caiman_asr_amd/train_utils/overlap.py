@@ -80,6 +80,35 @@ def _weight_gradient(dy2, x2):
     return dw
 
 
+# The joint projection on the hand-written MFMA GEMM (csrc/joint_gemm.hip): forward with the row log-sum-exp of the logits in
+# its epilogue (the loss then skips its own pass over the 5.3 GB of logits), input gradient with the same kernel.
+# CAIMAN_JOINT_GEMM: "0" library GEMMs (F.linear / torch.mm), "1" forward + input gradient, "fwd" forward only.
+JOINT_GEMM = __import__("os").environ.get("CAIMAN_JOINT_GEMM", "0")
+
+
+def _joint_gemm(a2, w, bias, want_lse):
+    """a2 [M, K] · w [N, K]^T (+ bias) -> (c [M, N], lse [M] f32 | None) through caiman_joint_fc_forward, or None when the
+    shapes are outside the kernel's geometry."""
+    from caiman_asr_amd import _lib
+
+    M, K = a2.shape
+    N = w.shape[0]
+    tag = _lib.dtype_tag(a2.dtype)
+    lib = _lib.lib()
+    if not (a2.is_cuda and a2.dtype in (torch.float16, torch.bfloat16) and a2.is_contiguous() and w.is_contiguous()
+            and w.dtype == a2.dtype and lib.caiman_joint_fc_supported(M, N, K, tag)):
+        return None
+    c = torch.empty((M, N), dtype=a2.dtype, device=a2.device)
+    lse = ws = None
+    if want_lse:
+        lse = torch.empty((M,), dtype=torch.float32, device=a2.device)
+        ws = torch.empty((lib.caiman_joint_fc_workspace_elems(M, N),), dtype=torch.float32, device=a2.device)
+    _lib.check(lib.caiman_joint_fc_forward(_lib.ptr(a2), _lib.ptr(w), None if bias is None else _lib.ptr(bias), _lib.ptr(c),
+                                           None if lse is None else _lib.ptr(lse), None if ws is None else _lib.ptr(ws),
+                                           M, N, K, tag, _lib.stream()))
+    return c, lse
+
+
 class _LinearTransposedBackward(torch.autograd.Function):
     """F.linear whose input gradient is computed against a [K, N] copy of the weight.  For the joint projection
     (rows x 768 x 8704, bf16) the library's `dY · Wᵀᵀ` (NT) kernel runs at 1.36 PF/s where the usual `dY · W` (NN)
@@ -90,6 +119,17 @@ class _LinearTransposedBackward(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if JOINT_GEMM != "0" and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+            x2 = x.reshape(-1, x.shape[-1])
+            out = _joint_gemm(x2 if x2.is_contiguous() else x2.contiguous(), weight.to(x.dtype).contiguous(),
+                              None if bias is None else bias.to(x.dtype).contiguous(), want_lse=True)
+            if out is not None:
+                from caiman_asr_amd.rnnt_ext.transducer.loss import offer_row_lse
+
+                c, lse = out
+                c = c.view(*x.shape[:-1], weight.shape[0])
+                offer_row_lse(c, lse)      # the loss picks the normalisers up instead of reading the logits again
+                return c
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -100,7 +140,9 @@ class _LinearTransposedBackward(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = weight.to(dy2.dtype).t().contiguous()           # [K, N]
-            dx = torch.mm(dy2, wt.t()).view(*dy.shape[:-1], weight.shape[1])
+            out = _joint_gemm(dy2 if dy2.is_contiguous() else dy2.contiguous(), wt, None, want_lse=False) \
+                if JOINT_GEMM == "1" else None
+            dx = (out[0] if out is not None else torch.mm(dy2, wt.t())).view(*dy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
             dw = _weight_gradient(dy2, x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:

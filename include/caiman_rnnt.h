@@ -316,6 +316,21 @@ int caiman_proj_gemm_supported(const caiman_proj_problem_t* problem, int dtype);
 int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n_problems, int dtype, int tile, caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Joint projection with the row log-sum-exp in its epilogue (csrc/joint_gemm.hip) — replaces
+ *   logits = self.joint_fc(h)                       training/caiman_asr_train/rnnt/model.py:409-439 (torch.nn.Linear)
+ *   denom  = logsumexp(logits)  inside the loss      training/lib/csrc/logsumexp.cu:65-105 (its call site
+ *                                                    training/lib/src/rnnt_ext/transducer/loss.py)
+ * C [M, N] = A [M, K] · W [N, K]^T + bias [N] (operands and C in `dtype`, bf16 / f16; fp32 accumulation); when `lse` is
+ * given, lse[m] = log sum_n exp(C[m][n]) of the STORED (rounded) row, fp32, through `workspace`
+ * (caiman_joint_fc_workspace_elems(M, N) floats).  lse == NULL: the plain product (the input gradient dY · W of the same
+ * projection is this call with the transposed weight copy as W).  N % 256 == 0, K % 128 == 0, A / W rows 16-byte aligned.
+ * ------------------------------------------------------------------------- */
+int64_t caiman_joint_fc_workspace_elems(int64_t M, int64_t N);
+int caiman_joint_fc_supported(int64_t M, int64_t N, int64_t K, int dtype);
+int caiman_joint_fc_forward(const void* A, const void* W, const void* bias, void* C, float* lse, float* workspace,
+                            int64_t M, int64_t N, int64_t K, int dtype, caiman_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not
  * vendored; call sites training/caiman_asr_train/rnnt/model.py:228-238,425-434; CPU
  * equivalent `torch_transducer_joint` + `relu_drop`, model.py:441-447,224).

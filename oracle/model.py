@@ -63,6 +63,35 @@ def rfb(x):
     return rb(rf(x))
 
 
+class _Cell(torch.autograd.Function):
+    """One LSTM cell update (training/lib/csrc/lstm.cu:85-135) whose backward is the reference's pointwise backward ON THE
+    STORED VALUES (lstm.cu:137-212: derivatives are taken on the ACTIVATED gates and on c as they sit in memory): with a
+    16-bit storage type the gates i, f, g, o and the new c are rounded before the backward pass reads them (csrc/lstm.hip
+    writes `v` = the activated gates and `cv`; the backward kernels read them back), while the forward value of h uses the
+    unrounded c.  storage None: plain autograd of the same formulas."""
+
+    @staticmethod
+    def forward(ctx, z, c_prev, storage):
+        H = z.shape[1] // 4
+        i, f, g, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), torch.sigmoid(z[:, 3 * H:])
+        c_new = i * g + f * c_prev
+        h = o * torch.tanh(c_new)
+
+        def r(t):
+            return t if storage is None else t.to(storage).to(t.dtype)
+
+        ctx.save_for_backward(r(i), r(f), r(g), r(o), c_prev, r(c_new))
+        return h, c_new
+
+    @staticmethod
+    def backward(ctx, dh, dc_next):
+        i, f, g, o, c_prev, c_cur = ctx.saved_tensors
+        ct = torch.tanh(c_cur)
+        dc = dh * o * (1 - ct * ct) + dc_next
+        dz = torch.cat([dc * g * (1 - i) * i, dc * c_prev * (1 - f) * f, dc * i * (1 - g * g), dh * ct * (1 - o) * o], 1)
+        return dz, dc * f, None
+
+
 def _linear(x, w, b):
     """autocast nn.Linear: 16-bit weight, bias and output; 16-bit output gradient"""
     return rfb(x @ rf(w).t() + rf(b))
@@ -83,9 +112,8 @@ def _lstm_stack(sd, prefix, x, num_layers, state=None):
         outs = []
         for t in range(T):
             pre = rb(pre_all[t] + h @ R.t())          # its gradient is dG[t], a stored row
-            i, f, g, o = pre.split(H, dim=1)
-            c_new = torch.sigmoid(i) * torch.tanh(g) + torch.sigmoid(f) * c
-            h = rf(torch.sigmoid(o) * torch.tanh(c_new))
+            h_new, c_new = _Cell.apply(pre, c, _STORAGE)
+            h = rf(h_new)
             c = rf(c_new)
             outs.append(h)
         x = torch.stack(outs, 0)

@@ -1,0 +1,115 @@
+"""profiles/<tag>_{kernel_stats.csv, pmc_traffic.json, summary.md} from the rocprofv3 passes of ONE command
+(tools/run/profile_config.sh runs them: a kernel-trace pass and four one-counter PMC passes, all with IDENTICAL program
+arguments, so that every pass sees the same launches).
+
+    python tools/profile_summary.py <dir with stats/ FETCH_SIZE/ WRITE_SIZE/ SQ_VALU_MFMA_BUSY_CYCLES/ GRBM_GUI_ACTIVE/> <tag> <steps traced> ["title"]
+
+Round-2 verdict, "profile hygiene": a byte count from one launch population divided by a time from another is not a
+rate.  Here a kernel's `traffic_bytes_per_launch` and `kernel_avg_us` are only combined into `hbm_side_rate_gbs` when the
+kernel was launched the same number of times in the kernel-trace pass and in every counter pass (`same_population`);
+the times come from the kernel-trace pass (kernels run serialised and slower under counter collection).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+NAMES = ("lstm_bwd_resident2_bt|lstm_fwd_resident_bt|lstm_fwd_resident_dma|lstm_bwd_resident2|lstm_bwd_resident|lstm_fwd_resident|"
+         "lstm_bwd_step_mfma|lstm_fwd_step_mfma|loss_bwd_colsum_kernel|loss_row_desc_kernel|loss_bwd_kernel|loss_fwd_kernel|lse_rows_kernel|"
+         "lse_partials_kernel|joint_fc_gemm_kernel|joint_bwd_kernel|joint_fwd_kernel|lamb_stage1|lamb_stage2|gnorm_kernel|beam_topk_kernel|"
+         "lstm_cell_kernel|gather_inputs_kernel|joint_act_kernel|proj_gemm_kernel|lstm_images_kernel|lstm_grad_deliver_kernel|logmel_kernel|"
+         "mel_normalize_kernel|dbias_rows_kernel")
+
+
+def short(name):
+    m = re.search("(" + NAMES + ")", name)
+    if m:
+        k = m.group(1)
+        if k == "proj_gemm_kernel" and "Lb1EEEv" in name:   # the CELL instantiation (last template argument true): LSTM step GEMM
+            return "proj_gemm_kernel[cell]"
+        return k
+    if name.startswith("Cijk") or name.startswith("Custom_Cijk"):
+        return "library_gemm"
+    if "rccl" in name.lower() or "nccl" in name.lower():
+        return "rccl"
+    return None
+
+
+def counter_pass(root, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(f"{root}/{counter}/**/*counter_collection.csv", recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row["Kernel_Name"])
+                if k is None or row["Counter_Name"] != counter:
+                    continue
+                acc[k][0] += float(row["Counter_Value"])
+                acc[k][1] += 1
+    return {k: {"avg": v[0] / v[1], "dispatches": v[1]} for k, v in acc.items()}
+
+
+def main(root, tag, steps, title=None):
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    steps = float(steps)
+    stats_csv = glob.glob(f"{root}/stats/**/*_kernel_stats.csv", recursive=True)[0]
+    shutil.copy(stats_csv, f"{prof}/{tag}_kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats_csv)))
+    agg = defaultdict(lambda: [0.0, 0])
+    for r in rows:
+        k = short(r["Name"]) or "other"
+        agg[k][0] += float(r["TotalDurationNs"])
+        agg[k][1] += int(r["Calls"])
+    counters = ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
+    S = {c: counter_pass(root, c) for c in counters}
+    pm = {"source": "rocprofv3 --kernel-trace --stats (times) and rocprofv3 --pmc <counter> --kernel-trace, ONE counter per pass, all passes "
+                    "with identical program arguments (tools/run/profile_config.sh); aggregated by tools/profile_summary.py",
+          "unit": "traffic_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads, "
+                  "MI355X_MICROARCH.md HBM section); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); "
+                  "hbm_side_rate_gbs = traffic_bytes_per_launch / kernel_avg_us, only where same_population"}
+    for k in sorted(set(S["FETCH_SIZE"]) | set(agg)):
+        if k == "other":
+            continue
+        f = S["FETCH_SIZE"].get(k)
+        e = {}
+        if k in agg:
+            e["launches_kernel_trace_pass"] = agg[k][1]
+            e["kernel_avg_us"] = round(agg[k][0] / agg[k][1] / 1e3, 2)
+            e["ms_per_step"] = round(agg[k][0] / steps / 1e6, 3)
+        if f:
+            w = S["WRITE_SIZE"].get(k, {"avg": 0.0, "dispatches": 0})
+            m = S["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, {"avg": 0.0, "dispatches": 0})
+            g = S["GRBM_GUI_ACTIVE"].get(k, {"avg": 0.0, "dispatches": 0})
+            counts = {f["dispatches"], w["dispatches"], m["dispatches"], g["dispatches"]}
+            e.update({"launches_counter_passes": sorted(counts), "fetch_size_kib_avg": round(f["avg"], 1),
+                      "write_size_kib_avg": round(w["avg"], 1), "traffic_bytes_per_launch": int((2 * f["avg"] + w["avg"]) * 1024),
+                      "mfma_util": round(m["avg"] / (1024 * g["avg"] / 8), 4) if g["avg"] else None})
+            same = k in agg and counts == {agg[k][1]}
+            e["same_population"] = same
+            if same:
+                e["hbm_side_rate_gbs"] = round(e["traffic_bytes_per_launch"] / (e["kernel_avg_us"] * 1e-6) / 1e9, 1)
+        pm[k] = e
+    json.dump(pm, open(f"{prof}/{tag}_pmc_traffic.json", "w"), indent=1)
+
+    tot = sum(v[0] for v in agg.values()) / steps / 1e6
+    launches = sum(v[1] for v in agg.values()) / steps
+    L = [f"# {title or tag} — rocprofv3\n",
+         f"Kernel-trace pass: {launches:.0f} launches and {tot:.2f} ms of kernel time per step / tick ({steps:.0f} traced; `{tag}_kernel_stats.csv`). "
+         f"Counter passes: one counter each, same arguments (`{tag}_pmc_traffic.json`).\n",
+         "| kernel | launches / step | ms / step | avg us | % of kernel time | HBM-side traffic / launch | MFMA busy | HBM-side rate |",
+         "|---|---|---|---|---|---|---|---|"]
+    for k, (ns, calls) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:24]:
+        e = pm.get(k, {}) if k != "other" else {}
+        tr = f"{e['traffic_bytes_per_launch'] / 1e6:.1f} MB" if "traffic_bytes_per_launch" in e else ""
+        mf = f"{100 * e['mfma_util']:.1f} %" if e.get("mfma_util") is not None else ""
+        rate = f"{e['hbm_side_rate_gbs'] / 1e3:.2f} TB/s" if "hbm_side_rate_gbs" in e else ("(populations differ)" if tr else "")
+        L.append(f"| `{k}` | {calls / steps:.1f} | {ns / steps / 1e6:.3f} | {ns / calls / 1e3:.1f} | {100 * ns / (tot * steps * 1e6):.1f} | {tr} | {mf} | {rate} |")
+    open(f"{prof}/{tag}_summary.md", "w").write("\n".join(L) + "\n")
+    print("\n".join(L))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
