@@ -365,7 +365,10 @@ def main():
     # inputs resident in HBM before the timed region
     dev_batches = [(f.to(dev), fl, t.to(dev), tl) for f, fl, t, tl in host_batches]
 
+    executed = [0]   # steps run in this process (pre-warm + warm-up + timed [+ feed]): what a profiler's trace holds
+
     def step(i, global_step):
+        executed[0] += 1
         feats, feat_lens_h, txt, txt_lens_h = dev_batches[i % n_distinct]
         lr_policy(optimizer, initial_lrs, 4e-4, global_step, 1632, 18000, 10880)
         feat_lens_d = feat_lens_h.to(dev, non_blocking=True)
@@ -573,6 +576,7 @@ def main():
                                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                             "avg_launch_ms": ms / n_launch, "launches": n_launch}
+        out["steps_executed_in_process"] = executed[0]
         native = _lib.lib()
         out["lstm_resident"] = {"launches": int(native.caiman_lstm_resident_launches()),
                                 "handoff_timeouts": int(native.caiman_lstm_resident_failures())}   # must be 0

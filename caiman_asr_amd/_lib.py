@@ -159,6 +159,7 @@ _SIGS = {
     "caiman_lstm_resident_failures": ([], ctypes.c_int),
     "caiman_lstm_resident_xcd_roles": ([I32], ctypes.c_int),
     "caiman_lstm_resident_bwd_split": ([I32], ctypes.c_int),
+    "caiman_lstm_resident_bt_dma": ([I32], ctypes.c_int),
     "caiman_lstm_resident_profile_bwd2": ([P], ctypes.c_int),
     "caiman_lstm_resident_set_failures": ([I32], ctypes.c_int),
     "caiman_lstm_resident_poison": ([P, P, P], ctypes.c_int),

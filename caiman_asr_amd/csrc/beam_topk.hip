@@ -9,6 +9,8 @@
 // One 256-thread workgroup per row.  The row (8704 logits = 17-35 KB) is read three times -- max, sum of
 // exponentials, selection -- and only the first read reaches HBM.  Selection: every thread keeps the k best
 // of its strided slice in registers, then k rounds of a workgroup arg-max merge the 256 sorted lists.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/caiman_beam.h"
 
@@ -124,6 +126,128 @@ __global__ __launch_bounds__(kTopkThreads) void beam_topk_kernel(const T* __rest
   if (tid == 0) blank_logp[row] = lp_blank;
 }
 
+
+// Fast path (16-bit logits, vocab % 8 == 0, vocab <= 8 * 256 * kRegChunks, 16-byte aligned rows, k <= 4): a beam round at
+// 2 000 streams has ~200 pending rows, fewer workgroups than CUs, so the kernel above is a pure latency chain -- 3 passes of
+// 34 scalar loads per thread with an fp32 division each, and a predicated 8-slot insertion per element: 42 us of a ~160 us
+// round (profiles/r03_decode_summary.md, before).  Here the row is read ONCE with 16-byte loads into registers (x / T kept as
+// fp32: 40 values per thread), the maximum, the sum of exponentials and the selection run from registers, and the insertion
+// list has exactly K slots.  Same arithmetic per element (x / T, expf, logf) and the same tie rule, so the selected tokens
+// and scores are those of the kernel above.
+constexpr int kRegChunks = 5;   // 16-byte pieces per thread: vocab <= 10 240
+
+template <typename T, int K>
+__global__ __launch_bounds__(kTopkThreads) void beam_topk_reg_kernel(const T* __restrict__ logits, TopkParams p,
+                                                                    float* __restrict__ top_scores,
+                                                                    int32_t* __restrict__ top_tokens,
+                                                                    float* __restrict__ blank_logp) {
+  using v8 = __attribute__((ext_vector_type(8))) T;
+  __shared__ float red_f[kTopkThreads / kWave];
+  __shared__ Cand red_c[kTopkThreads / kWave];
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * p.row_stride;
+  const int tid = threadIdx.x;
+  const float NEG_INF = -INFINITY;
+  const int chunks = (int)(p.vocab >> 3);
+
+  float v[kRegChunks][8];
+  v8 raw[kRegChunks];
+#pragma unroll
+  for (int c = 0; c < kRegChunks; ++c) {
+    const int ch = tid + c * kTopkThreads;
+    if (ch < chunks) raw[c] = *reinterpret_cast<const v8*>(x + (int64_t)ch * 8);
+  }
+  float m = NEG_INF;
+#pragma unroll
+  for (int c = 0; c < kRegChunks; ++c) {
+    const bool on = tid + c * kTopkThreads < chunks;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[c][e] = on ? (float)raw[c][e] / p.temp : NEG_INF;
+      m = fmaxf(m, v[c][e]);
+    }
+  }
+  m = block_reduce<kTopkThreads / kWave>(m, [](float a, float b) { return fmaxf(a, b); }, red_f);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kRegChunks; ++c) {
+    const bool on = tid + c * kTopkThreads < chunks;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += on ? expf(v[c][e] - m) : 0.f;
+  }
+  s = block_reduce<kTopkThreads / kWave>(s, [](float a, float b) { return a + b; }, red_f);
+  const float lse = m + logf(s);
+
+  float lp_blank = (float)x[p.blank_idx] / p.temp - lse;
+  float lp_eos = NEG_INF;
+  if (p.eos_mode != CAIMAN_EOS_NONE) {
+    lp_eos = (float)x[p.eos_idx] / p.temp - lse;
+    if (p.eos_mode == CAIMAN_EOS_IGNORE) {
+      lp_eos = NEG_INF;
+    } else if (p.eos_mode == CAIMAN_EOS_BLANK) {
+      const float hi = fmaxf(lp_blank, lp_eos), lo = fminf(lp_blank, lp_eos);
+      lp_blank = hi == NEG_INF ? NEG_INF : hi + log1pf(expf(lo - hi));
+      lp_eos = NEG_INF;
+    } else {
+      lp_eos *= p.eos_alpha;
+      if (!(lp_eos > p.eos_log_beta)) lp_eos = NEG_INF;
+    }
+  }
+
+  Cand mine[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) mine[q] = {NEG_INF, INT32_MAX};
+#pragma unroll
+  for (int c = 0; c < kRegChunks; ++c) {
+    const int ch = tid + c * kTopkThreads;
+    if (ch < chunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int32_t j = ch * 8 + e;
+        Cand cd{v[c][e] - lse, j};
+        if (j == p.blank_idx) cd.v = lp_blank;
+        if (p.eos_mode != CAIMAN_EOS_NONE && j == p.eos_idx) cd.v = lp_eos;
+        if (cd.v != cd.v) cd.v = NEG_INF;  // NaN never wins
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          if (q < p.k && better(cd.v, cd.i, mine[q].v, mine[q].i)) {
+            const Cand t = mine[q];
+            mine[q] = cd;
+            cd = t;
+          }
+        }
+      }
+    }
+  }
+  int head = 0;
+  for (int r = 0; r < p.k; ++r) {
+    Cand c{NEG_INF, INT32_MAX};
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      if (q == head) c = mine[q];
+    Cand w = c;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(w.v, off, kWave);
+      const int32_t oi = __shfl_xor(w.i, off, kWave);
+      if (better(ov, oi, w.v, w.i)) w = {ov, oi};
+    }
+    if ((tid & (kWave - 1)) == 0) red_c[tid / kWave] = w;
+    __syncthreads();
+    Cand g = red_c[0];
+#pragma unroll
+    for (int q = 1; q < kTopkThreads / kWave; ++q)
+      if (better(red_c[q].v, red_c[q].i, g.v, g.i)) g = red_c[q];
+    if (c.i == g.i && g.i != INT32_MAX) ++head;
+    if (tid == 0) {
+      top_scores[row * p.k + r] = g.v;
+      top_tokens[row * p.k + r] = g.i == INT32_MAX ? 0 : g.i;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) blank_logp[row] = lp_blank;
+}
+
 }  // namespace
 }  // namespace caiman
 
@@ -151,6 +275,15 @@ extern "C" int caiman_beam_topk(const void* logits, int64_t n, int64_t vocab, in
       set_error("beam_topk: f64 logits are not supported");
       return CAIMAN_ERR_UNSUPPORTED;
     } else {
+      if constexpr (sizeof(scalar_t) == 2) {
+        static const bool reg_path = !(std::getenv("CAIMAN_TOPK_REG") && std::atoi(std::getenv("CAIMAN_TOPK_REG")) == 0);
+        if (reg_path && k <= 4 && vocab % 8 == 0 && vocab <= 8 * kTopkThreads * kRegChunks && row_stride % 8 == 0 &&
+            (reinterpret_cast<uintptr_t>(logits) & 15u) == 0) {
+          hipLaunchKernelGGL((beam_topk_reg_kernel<scalar_t, 4>), dim3((unsigned)n), dim3(kTopkThreads), 0, st,
+                             static_cast<const scalar_t*>(logits), p, top_scores, top_tokens, blank_logp);
+          return check_launch("caiman_beam_topk");
+        }
+      }
       hipLaunchKernelGGL((beam_topk_kernel<scalar_t>), dim3((unsigned)n), dim3(kTopkThreads), 0, st,
                          static_cast<const scalar_t*>(logits), p, top_scores, top_tokens, blank_logp);
       return check_launch("caiman_beam_topk");

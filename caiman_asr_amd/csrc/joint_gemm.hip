@@ -31,6 +31,9 @@
 // shuffles (the four lanes that share a row) instead of a transpose.
 // Workgroups are dealt to tiles through the XCD remap of the guide (T1, bijective form): the eight XCDs each get a
 // contiguous run of tiles, M-tile major, so the 34 workgroups that share an activation panel share an L2.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace caiman {
@@ -51,11 +54,11 @@ __device__ __forceinline__ f32x4 jmfma(jfrag<f16_t>::type a, jfrag<f16_t>::type 
 constexpr int JBM = 256, JBN = 256, JBK = 32, JNW = 8;
 constexpr int JTM = 8, JTN = 4;   // 16 x 16 blocks of a wave tile: 128 rows, 64 columns
 
-template <typename T, bool LSE>
+template <typename T, bool LSE, bool PRIO>
 __global__ __launch_bounds__(64 * JNW, 1) void joint_fc_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                                    const T* __restrict__ bias, T* __restrict__ C,
                                                                    float* __restrict__ pmax, float* __restrict__ psum, int M,
-                                                                   int N, int K, int tiles_n) {
+                                                                   int N, int K, int tiles_n, int tiles_m, int group) {
   using frag = typename jfrag<T>::type;
   __shared__ __attribute__((aligned(1024))) T sA0[JBM * JBK], sA1[JBM * JBK], sA2[JBM * JBK], sA3[JBM * JBK];
   __shared__ __attribute__((aligned(1024))) T sW0[JBN * JBK], sW1[JBN * JBK], sW2[JBN * JBK], sW3[JBN * JBK];
@@ -68,7 +71,17 @@ __global__ __launch_bounds__(64 * JNW, 1) void joint_fc_gemm_kernel(const T* __r
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int m0 = (t / tiles_n) * JBM, n0 = (t % tiles_n) * JBN;
+  // tile order: groups of `group` M-tiles; inside a group N-tile major, M-tile minor.  The workgroups an XCD runs at the same
+  // time (32 consecutive tiles) then share a few weight panels AND a few activation panels (both stay in the XCD's 4 MB L2),
+  // instead of one activation panel and all 34 weight panels (13 MB: served from the Infinity Cache for every M-tile).
+  int tm, tn;
+  {
+    const int per = group * tiles_n, g = t / per, w_ = t - g * per;
+    const int gm = min(group, tiles_m - g * group);
+    tn = w_ / gm;
+    tm = g * group + (w_ - tn * gm);
+  }
+  const int m0 = tm * JBM, n0 = tn * JBN;
 
   // per-lane DMA sources as 32-bit byte offsets from wave-uniform bases.  A stage holds 16 blocks of 16 rows per operand;
   // wave w brings blocks w and w + 8; lane l of a block brings the piece that belongs at (row l >> 2, position l & 3).
@@ -118,16 +131,19 @@ __global__ __launch_bounds__(64 * JNW, 1) void joint_fc_gemm_kernel(const T* __r
     afo[b] = row * JBK + ((kq ^ ((row >> 2) & 3)) * 8);
   }
 
+  constexpr bool prio = PRIO;
   auto compute = [&](const T* lA, const T* lW) {
     frag wf[JTN], af[JTM];
 #pragma unroll
     for (int a = 0; a < JTN; ++a) wf[a] = *reinterpret_cast<const frag*>(lW + wfo[a]);
 #pragma unroll
     for (int b = 0; b < JTM; ++b) af[b] = *reinterpret_cast<const frag*>(lA + afo[b]);
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int b = 0; b < JTM; ++b)
 #pragma unroll
       for (int a = 0; a < JTN; ++a) acc[a][b] = jmfma(wf[a], af[b], acc[a][b]);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
   // s_waitcnt through the builtin (the compiler's own wait-count bookkeeping sees it).  simm16 = vmcnt[3:0] | expcnt 7 << 4 |
@@ -241,19 +257,27 @@ __global__ __launch_bounds__(256) void lse_partials_kernel(const float* __restri
 template <typename T>
 int launch_joint_fc(const T* A, const T* W, const T* bias, T* C, float* lse, float* ws, int64_t M, int64_t N, int64_t K,
                     hipStream_t s) {
-  const int tiles_n = (int)(N / JBN);
-  const int64_t tiles = (M + JBM - 1) / JBM * tiles_n;
+  const int tiles_n = (int)(N / JBN), tiles_m = (int)((M + JBM - 1) / JBM);
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
   const int NP = (int)(N / 64);
+  // measurement knobs (tools/joint_gemm_bench.py): M-tiles per group of the tile order, s_setprio around the MFMA clusters
+  // measured (tools/joint_gemm_bench.py, 304 000 x 768 x 8704): forward + LSE 5.57 ms M-tile major, 5.18 in groups of 8, 5.57 in
+  // groups of 16; the input gradient (N = 768: three N-tiles) 3.63 / 3.76 / 3.91 -- so 8 with the epilogue, 1 without
+  static const int group_env = std::getenv("CAIMAN_JOINT_GROUP") ? std::atoi(std::getenv("CAIMAN_JOINT_GROUP")) : 0;
+  static const bool prio = std::getenv("CAIMAN_JOINT_PRIO") != nullptr && std::atoi(std::getenv("CAIMAN_JOINT_PRIO")) != 0;
+  const int group = std::max(1, std::min(group_env > 0 ? group_env : (lse ? 8 : 1), tiles_m));
+  float* pmax = lse ? ws : nullptr;
+  float* psum = lse ? ws + M * NP : nullptr;
+#define CAIMAN_JGEMM(L, P)                                                                                                \
+  hipLaunchKernelGGL((joint_fc_gemm_kernel<T, L, P>), dim3((unsigned)tiles), dim3(64 * JNW), 0, s, A, W, bias, C, pmax, psum, \
+                     (int)M, (int)N, (int)K, tiles_n, tiles_m, group)
   if (lse) {
-    float* pmax = ws;
-    float* psum = ws + M * NP;
-    hipLaunchKernelGGL((joint_fc_gemm_kernel<T, true>), dim3((unsigned)tiles), dim3(64 * JNW), 0, s, A, W, bias, C, pmax, psum,
-                       (int)M, (int)N, (int)K, tiles_n);
+    if (prio) CAIMAN_JGEMM(true, true); else CAIMAN_JGEMM(true, false);
     hipLaunchKernelGGL(lse_partials_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, pmax, psum, lse, M, NP);
   } else {
-    hipLaunchKernelGGL((joint_fc_gemm_kernel<T, false>), dim3((unsigned)tiles), dim3(64 * JNW), 0, s, A, W, bias, C, nullptr,
-                       nullptr, (int)M, (int)N, (int)K, tiles_n);
+    if (prio) CAIMAN_JGEMM(false, true); else CAIMAN_JGEMM(false, false);
   }
+#undef CAIMAN_JGEMM
   return check_launch("joint projection GEMM");
 }
 

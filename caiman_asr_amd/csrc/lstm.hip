@@ -1085,6 +1085,247 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, in
   }
 }
 
+// Batch tiles with the operands of tile-step i + 1 arriving under the MFMAs of tile-step i (H = 512, 1024; 32 < B <= 128).
+// lstm_fwd_resident_bt spends 1.25 of its 3.6 us per tile-step pulling the 64 KB h tile through staging registers before
+// the first MFMA can issue.  Here every operand of a tile-step comes by LDS-DMA into one of TWO buffer sets -- the h tile
+// (as in lstm_fwd_resident_dma) and the tile's pre-activations (32 rows x 64 B per wave) -- and c never leaves the CU (a
+// lane keeps the four cells it updates in LDS, one slot per tile).  While the workgroup multiplies tile-step i out of one
+// set, the DMAs of tile-step i + 1 fill the other, provided that tile's hand-off counter has already reached its target
+// when tile-step i starts (one relaxed load by one lane, broadcast through LDS behind a barrier).  With 2 - 4 tiles per
+// timestep it almost always has: the peers produced tile bt + 1 of the previous timestep ntiles - 1 tile-steps ago.  When
+// it has not, the next tile-step spins and gathers at its start, as lstm_fwd_resident_bt does.
+// No register-destination global load is left in the loop: next to LDS-DMAs in flight the compiler answers any wait for
+// such a load with vmcnt(0), which would drain the prefetch (guide 5, "three .s-level traps", b).  For the same reason the
+// DMA count per tile-step is fixed (a gather under a condition makes the wait counts fall back to vmcnt(0) at the join):
+// when the next tile is not complete, the current one is gathered once more into the other set, harmlessly.  The buffer
+// sets are separate LDS objects and the loop is unrolled by two with the sets named statically.
+template <typename T, bool HARD, int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host, unsigned* scrub) {
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32;
+  constexpr int NST = H / 512, LDW = 512 + 8, KPS = 16;
+  static_assert(H % 512 == 0 && NST >= 1 && NST <= 2, "double-buffered batch-tile kernel: H = 512 or 1024");
+  // ONE LDS object per buffer set (stage buffers, then the pre-activations [wave][row][8 units x 4 gates]): with DMAs in flight to
+  // more than two distinct LDS objects the compiler puts a vmcnt(0) in front of the next DMA (seen in the ISA), which would
+  // serialise the gather
+  __shared__ __attribute__((aligned(16))) T bufE[NST * 32 * LDW + 4 * 32 * 32];
+  __shared__ __attribute__((aligned(16))) T bufO[NST * 32 * LDW + 4 * 32 * 32];
+  __shared__ __attribute__((aligned(16))) T cells[kResMaxTiles * 256 * 4];            // [tile][thread][rt][ct]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tr = reinterpret_cast<T*>(smem);                       // [4 waves][2: h, c][32 rows][8 units]
+  int* flag = reinterpret_cast<int*>(tr + 4 * 2 * 32 * 8);  // [0] abort, [1] next tile-step's rows are ready
+
+  int slot, j;
+  res_role<NKS>(slot, j);
+  const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytesBT / sizeof(unsigned)));
+  if (nsteps <= 0) return;
+  const int nwg = NKS;
+  const int ntiles = (B + 31) / 32;
+  unsigned* fail_dev = sync + kMaxSlots * kResMaxTiles * 12 * kResCounterStride;
+  auto counter = [&](int bt) -> unsigned* { return sync + ((slot * kResMaxTiles + bt) * 12) * kResCounterStride; };
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  const int u0 = j * 32 + wave * 8;   // first hidden unit of this wave
+
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rtile[slot];
+    const int n = (r & 3) * 4 + (r >> 2);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)j * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) wreg[rt][ks] = *reinterpret_cast<const frag*>(Rt + ((blk * NKS + ks) * 16 + n) * 32 + 8 * kq);
+    }
+  }
+  // this lane's cells of every tile: unit u0 + rt*4 + kq, batch row 32 bt + ct*16 + r (rows past B: the last row's, never stored)
+  {
+    const T* c0 = w.c[slot];
+    for (int t = 0; t < ntiles; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int b = t * 32 + ct * 16 + r, bc = b < B ? b : B - 1;
+          cells[(t * 256 + tid) * 4 + rt * 2 + ct] = c0[(int64_t)bc * H + u0 + rt * 4 + kq];
+        }
+  }
+  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+  T* trh = tr + wave * (2 * 32 * 8);
+  T* trc = trh + 32 * 8;
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+
+  // operands of tile-step (s_, bt_) -> one buffer set: the h tile (8 DMA instructions per wave and stage) and this wave's
+  // 32 x 64 B of pre-activations (2 instructions: lane = (row lane >> 2 of 16, 16-byte piece lane & 3)).  Rows past B re-read
+  // the last row (never stored).
+  auto gather = [&](T* b0, int s_, int bt_, int sg_, int btg_) {
+    T* gb = b0 + NST * 32 * LDW;
+    const T* src = w.y[slot] + so * s_;
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      T* bq = b0 + q * 32 * LDW;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int bl = wave + 4 * i, b = bt_ * 32 + bl, bs = b < B ? b : B - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (int64_t)bs * H + q * 512 + lane * 8),
+            (__attribute__((address_space(3))) void*)(bq + bl * LDW), 16, 0, 16);
+      }
+    }
+    const T* gs = w.g[slot] + go * sg_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int bl = i * 16 + (lane >> 2), b = btg_ * 32 + bl, bs = b < B ? b : B - 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(gs + ((int64_t)bs * H + u0) * 4 + (lane & 3) * 8),
+          (__attribute__((address_space(3))) void*)(gb + (wave * 32 + i * 16) * 32), 16, 0, 0);
+    }
+  };
+
+  int s = 0, bt = 0;
+  bool have = false, aborted = false;     // have: this tile-step's operands were gathered during the previous one
+  auto body = [&](T* c0, T* n0) {
+    const T* cg = c0 + NST * 32 * LDW;
+    T* g = w.g[slot] + go * s;
+    unsigned* cnt = counter(bt);
+    const int row0 = bt * 32;
+    const int bt_n = bt + 1 < ntiles ? bt + 1 : 0, s_n = bt + 1 < ntiles ? s : s + 1;
+    if (!have) {   // (first tile-step, or the tile was not complete when the previous tile-step looked) wait, then gather now
+      if (s > 0 && tid == 0) {
+        if (!res_wait(cnt, (unsigned)nwg * (unsigned)s, fail_dev, fail_host)) flag[0] = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (flag[0]) { aborted = true; return; }
+      gather(c0, s, bt, s, bt);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share has landed
+    }
+    // (have: the DMAs of this tile-step were issued a tile-step ago and every wave drained them before that one's last barrier)
+    if (tid == 0) {   // is the next tile-step's tile complete already?  (one relaxed load; the rows themselves come by sc1 DMA)
+      int rdy = 0;
+      if (s_n < nsteps)
+        rdy = s_n == 0 || __hip_atomic_load(counter(bt_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nwg * (unsigned)s_n;
+      flag[1] = rdy;
+    }
+    // waits through the builtin, not asm: the compiler's own wait-count bookkeeping must SEE that nothing is outstanding here --
+    // after an asm wait it still believes the previous tile-step's stores pending and protects their data registers with a
+    // vmcnt(0) of its own in the middle of the DMAs issued below (seen in the ISA: it drained the prefetch)
+    __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    const bool ready = flag[1] != 0;
+    const bool more = s_n < nsteps;
+    gather(n0, ready ? s_n : s, ready ? bt_n : bt, more ? s_n : s, more ? bt_n : bt);     // flies under the MFMAs below
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      const T* bq = c0 + q * 32 * LDW;
+      constexpr int KB = 4, NB_ = KPS / KB;
+      frag bb[2][KB][2];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        bb[0][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + i * 32 + kq * 8);
+        bb[0][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + i * 32 + kq * 8);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB_; ++nb) {
+        if (nb + 1 < NB_) {
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = (nb + 1) * KB + i;
+            bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + ks * 32 + kq * 8);
+            bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + ks * 32 + kq * 8);
+          }
+        }
+        asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                          "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                     :: "memory");
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const int ks = q * KPS + nb * KB + i;
+          acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+          acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+          acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+          acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+        }
+      }
+    }
+    // cell update, lane-local: acc register q = gate q of (unit kq of the row tile, batch row r of the column tile)
+    T* cl = cells + (bt * 256 + tid) * 4;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int b = ct * 16 + r, ul = rt * 4 + kq;   // row within the tile
+        const g4 gv = *reinterpret_cast<const g4*>(cg + (wave * 32 + b) * 32 + ul * 4);
+        const float pi = static_cast<float>(gv[0]) + acc[rt][ct][0];
+        const float pf = static_cast<float>(gv[1]) + acc[rt][ct][1];
+        const float pg = static_cast<float>(gv[2]) + acc[rt][ct][2];
+        const float po = static_cast<float>(gv[3]) + acc[rt][ct][3];
+        const float ig = FastAct<HARD>::sigm(pi), fg = FastAct<HARD>::sigm(pf);
+        const float gg = FastAct<HARD>::tanhv(pg), og = FastAct<HARD>::sigm(po);
+        const float c = ig * gg + fg * static_cast<float>(cl[rt * 2 + ct]);
+        const T cv = static_cast<T>(c);
+        const T yv = static_cast<T>(og * FastAct<HARD>::tanhv(c));
+        cl[rt * 2 + ct] = cv;
+        trh[b * 8 + ul] = yv;
+        trc[b * 8 + ul] = cv;
+        if (row0 + b < B) {
+          g4 v;
+          v[0] = static_cast<T>(ig); v[1] = static_cast<T>(fg); v[2] = static_cast<T>(gg); v[3] = static_cast<T>(og);
+          *reinterpret_cast<g4*>(g + ((int64_t)(row0 + b) * H + u0 + ul) * 4) = v;
+        }
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int bl = lane >> 1, half = lane & 1, b = row0 + bl;
+      if (b < B) {
+        const g4 hv = *reinterpret_cast<const g4*>(trh + bl * 8 + half * 4);
+        const g4 cv = *reinterpret_cast<const g4*>(trc + bl * 8 + half * 4);
+        const int64_t e = (int64_t)b * H + u0 + half * 4;
+        unsigned long long hbits;
+        __builtin_memcpy(&hbits, &hv, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(w.y[slot] + so * (s + 1) + e), hbits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
+        if (w.ymask[slot]) {
+          g4 mv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
+            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
+          }
+          *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
+        }
+        if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
+          const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+          T* h_out = w.hring[slot] + ((w.parity[slot] + nsteps) & 1) * hsz;
+          *reinterpret_cast<g4*>(h_out + tiled_index(b, u0 + half * 4, NKS)) = hv;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): every storing wave drains (and the next tile-step's DMAs have landed)
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    have = ready;
+    bt = bt_n;
+    s = s_n;
+  };
+  const int total = nsteps * ntiles;
+  for (int i = 0; i < total && !aborted; i += 2) {
+    body(bufE, bufO);
+    if (i + 1 < total && !aborted) body(bufO, bufE);
+  }
+}
+
 // Forward resident kernel with the h row gathered by LDS-DMA (H = 512, 1024, 1536): lstm_fwd_resident pulls the row
 // through staging registers (32 * H / 8 / 256 16-byte pieces per thread: 96 VGPRs at H = 1536), which, next to
 // 2 * H / 32 resident weight fragments per wave (384 VGPRs at H = 1536), does not fit the 512 registers of a wave.  Here
@@ -2636,6 +2877,8 @@ unsigned* res_begin_bt(ResState* st, hipStream_t s, unsigned** scrub) {
   return sync;
 }
 
+std::atomic<int> g_res_bt_dma{1};   // batch-tile forward kernel with double-buffered DMA operands (lstm_fwd_resident_bt_dma)
+
 template <typename T, bool HARD>
 bool try_fwd_resident_bt(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
   *err = CAIMAN_OK;
@@ -2650,6 +2893,14 @@ bool try_fwd_resident_bt(const FwdSlots<T>& w, int n_slots, int n_launches, int6
   unsigned* scrub = nullptr;
   unsigned* sync = res_begin_bt(st, s, &scrub);
   const dim3 grid = res_grid(nks, n_slots, st->cus);
+  if (g_res_bt_dma.load(std::memory_order_relaxed) && (nks == 16 || nks == 32)) {
+    const size_t lds = (size_t)(4 * 2 * 32 * 8) * sizeof(T) + 16;   // the operand buffers are static LDS objects of the kernel
+    if (nks == 16) hipLaunchKernelGGL((lstm_fwd_resident_bt_dma<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, scrub);
+    else hipLaunchKernelGGL((lstm_fwd_resident_bt_dma<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, scrub);
+    res_end(st, s);
+    *err = check_launch("lstm resident forward (batch tiles, double-buffered)");
+    return true;
+  }
   const size_t lds = res_fwd_lds<T>((int)H);
 #define CAIMAN_RESBT(NKV)                                                                                            \
   do {                                                                                                               \
@@ -2852,6 +3103,10 @@ extern "C" int caiman_lstm_resident_mode(int mode) {
 extern "C" int caiman_lstm_resident_xcd_roles(int on) { return caiman::g_res_xcd_roles.exchange(on ? 1 : 0); }
 
 extern "C" int caiman_lstm_resident_bwd_split(int on) { return caiman::g_res_bwd_split.exchange(on ? 1 : 0); }
+
+// Batch-tile forward kernel: 1 = operands of the next tile-step by LDS-DMA under the MFMAs of the current one (default),
+// 0 = the register-staged kernel of round 2.  Returns the previous setting.  Results are bit-identical.
+extern "C" int caiman_lstm_resident_bt_dma(int on) { return caiman::g_res_bt_dma.exchange(on ? 1 : 0); }
 
 // Mode 2 phase timers of the 2-D split backward kernel (workgroup 0 of slot 0), 10 ns ticks summed over timesteps:
 // out8[0..5] = {wait for the quarter's producers, gather + MFMA, partial blocks out + drain, wait for the group,

@@ -247,3 +247,30 @@ def test_layer_to_xcd_placement_option_does_not_change_the_results(T, B, H):
         lib.caiman_lstm_resident_xcd_roles(prev)
     for x1, x2 in zip(a, b):
         assert torch.equal(x1, x2)
+
+
+@pytest.mark.parametrize("T,B,H,hard", [(9, 128, 1024, False), (11, 70, 512, False), (7, 33, 1024, True)])
+def test_double_buffered_batch_tile_forward_kernel_is_bit_identical_to_the_register_staged_one(T, B, H, hard):
+    """lstm_fwd_resident_bt_dma (operands of tile-step i + 1 by LDS-DMA under the MFMAs of tile-step i) must reproduce
+    lstm_fwd_resident_bt exactly -- same MFMA order, same roundings -- including ragged last tiles and repeated launches
+    (the prefetch decision depends on timing; the results must not)."""
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(T * B + H)
+    dt = torch.bfloat16
+    R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dt)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    y0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+    delta = torch.randn(T, B, H, generator=g).to(dt)
+    outs = []
+    for mode in (1, 0, 1, 1):
+        prev = lib.caiman_lstm_resident_bt_dma(mode)
+        try:
+            outs.append(_resident_fwd_bwd(R, gates, c0, y0, delta, hard))
+        finally:
+            lib.caiman_lstm_resident_bt_dma(prev)
+    for other in outs[1:]:
+        for name, a, b in zip(("gates", "c", "y", "dG", "dbias"), outs[0], other):
+            assert torch.equal(a, b), name

@@ -54,6 +54,13 @@ def counter_pass(root, counter):
 
 def main(root, tag, steps, title=None):
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    if steps == "auto":   # the program's own JSON line in the kernel-trace pass's log says how many steps / ticks it ran
+        steps = None
+        for ln in open(f"{root}/stats.log"):
+            if ln.lstrip().startswith("{"):
+                d = json.loads(ln)
+                steps = d.get("steps_executed_in_process") or (d.get("ticks", 0) + d.get("warmup_ticks", 0)) or None
+        assert steps, "no step count in stats.log: give it on the command line"
     steps = float(steps)
     stats_csv = glob.glob(f"{root}/stats/**/*_kernel_stats.csv", recursive=True)[0]
     shutil.copy(stats_csv, f"{prof}/{tag}_kernel_stats.csv")
