@@ -1447,10 +1447,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_dma(FwdSlots<T> w, i
 #pragma unroll
     for (int q = 0; q < NST; ++q) {
       // this wave's rows of stage q have landed (the later stages' 8 instructions each may still fly) and its LDS reads
-      // of the stage before have returned; behind the bare barrier that holds for every wave
-      if (q + 2 < NST) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // of the stage before have returned; behind the bare barrier that holds for every wave.  The waits go through the
+      // builtin (simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): after an asm wait the compiler's own
+      // bookkeeping still believed the previous timestep's stores pending and put a vmcnt(0) of its own behind the first
+      // barrier -- every stage had landed before the first MFMA issued (seen in the ISA)
+      if (q + 2 < NST) { __builtin_amdgcn_s_waitcnt(0x4070); __builtin_amdgcn_s_barrier(); }
+      else if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x0078); __builtin_amdgcn_s_barrier(); }
+      else { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }
       if (q == NST - 1) { CAIMAN_PROF_MARK(1) }
       const T* bq = ring(q);
       constexpr int KB = NKS > 32 ? KBW : 4, NB_ = KPS / KB;
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_dma(FwdSlots<T> w, i
       }
     }
     CAIMAN_PROF_MARK(2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // every storing wave drains before the workgroup signals
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CAIMAN_PROF_MARK(3)
@@ -2021,9 +2024,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       for (int q = 0; q < NST; ++q) {
         // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
         // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
-        if (q + 2 < NST) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (q + 2 < NST) { __builtin_amdgcn_s_waitcnt(0x4070); __builtin_amdgcn_s_barrier(); }
+        else if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x0078); __builtin_amdgcn_s_barrier(); }
+        else { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }
         const T* bq = ring(q);
         constexpr int KB = NKS > 32 ? KBW : 4, NB_ = KPS / KB;   // H = 1536: 384 weight registers leave room for one or two k-steps ahead
         frag bb[2][KB][2];
@@ -2081,7 +2084,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
           for (int ct = 0; ct < 2; ++ct)
             res_store16(acc[rt][ct], rp, ((ct * 16 + r) * 32 + rt * 16 + kg * 4) * (int)sizeof(float));
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // every storing wave drains before the workgroup signals
       __syncthreads();
       if (tid == 0) {
         __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2155,7 +2158,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       }
     }
     CAIMAN_PROF2(4)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(qc_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CAIMAN_PROF2(5)
@@ -2325,8 +2328,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
       for (int q = 0; q < NST; ++q) {
         // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
         // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
-        if (q + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x0078); __builtin_amdgcn_s_barrier(); }
+        else { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }
         const T* bq = ring(q);
         constexpr int KB = 4, NB_ = KPS / KB;
         frag bb[2][KB][2];
@@ -2379,7 +2382,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
           for (int ct = 0; ct < 2; ++ct)
             res_store16(acc[rt][ct], rp, ((ct * 16 + r) * 32 + rt * 16 + kg * 4) * (int)sizeof(float));
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup signals
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // every storing wave drains before the workgroup signals
       __syncthreads();
       if (tid == 0) {
         __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2445,7 +2448,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
       for (int q = 0; q < 4; ++q) dv[q] = dcs[q];
       *reinterpret_cast<f32x4*>(w.dC[slot] + eoff) = dv;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(qc_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    }
