@@ -1982,16 +1982,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
     const T* delta = w.delta[slot] - d_st * s;
     T* dG = w.dG[slot] - go * s;
     const bool has_in = s > 0 || has_in0;
+    // The epilogue's operands (none depends on the recurrence) are loaded BEHIND the DMAs of the gather, not in front of the
+    // wait as in round 2: prefetched early they sat in accumulator registers that the MFMA phase wanted, and the compiler
+    // protected them with a vmcnt(0) in the middle of the DMA issue -- 12 of the 16 DMAs had to land before the last four
+    // were issued (seen in the ISA).  Now they travel under the MFMAs.  EXACTLY five unconditional load instructions (rows
+    // past B read the last row; the results are only used under `ep`): the stage waits below count them.
     frag gv0, gv1;
     g4 cpv, ccv, dlv;
-    if (ep) {   // none of these depends on the recurrence: they travel while the workgroup waits
-      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4u);
-      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4u + 8u);
-      cpv = *reinterpret_cast<const g4*>(c_prev + eoff);
-      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoff);
-      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)eb * d_sb + u);
-    }
+    const unsigned eoffc = (unsigned)((eb < B ? eb : B - 1) * H + u);
+    auto load_epilogue_operands = [&]() {
+      gv0 = *reinterpret_cast<const frag*>(g + eoffc * 4u);
+      gv1 = *reinterpret_cast<const frag*>(g + eoffc * 4u + 8u);
+      cpv = *reinterpret_cast<const g4*>(c_prev + eoffc);
+      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoffc);
+      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)(eb < B ? eb : B - 1) * d_sb + u);
+    };
     float psum[4] = {0.f, 0.f, 0.f, 0.f};   // (dG[t+1] R) for this thread's 4 units, all of K
+    if (!has_in) load_epilogue_operands();
     if (has_in) {
       if (s > 0 && tid == 0) {
         if (!res_wait(qc_wait, (unsigned)PPQ * (unsigned)s, fail_dev, fail_host)) *flag = 1;
@@ -2015,6 +2022,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // issue order pinned: [8 NST DMAs][5 loads] -- the wait counts below depend on it
+      load_epilogue_operands();
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 acc[2][2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -2022,11 +2032,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
         for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NST; ++q) {
-        // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
-        // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
-        if (q + 2 < NST) { __builtin_amdgcn_s_waitcnt(0x4070); __builtin_amdgcn_s_barrier(); }
-        else if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x0078); __builtin_amdgcn_s_barrier(); }
-        else { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }
+        // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each and the 5 loads may still
+        // fly) and its LDS reads of the stage before have returned; behind the bare barrier that holds for every wave.
+        // simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 0 << 8 | vmcnt[5:4] << 14: vmcnt 21 / 13 / 5.
+        if (q + 2 < NST) { __builtin_amdgcn_s_waitcnt(0x4075); __builtin_amdgcn_s_barrier(); }
+        else if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x007D); __builtin_amdgcn_s_barrier(); }
+        else { __builtin_amdgcn_s_waitcnt(0x0075); __builtin_amdgcn_s_barrier(); }
         const T* bq = ring(q);
         constexpr int KB = NKS > 32 ? KBW : 4, NB_ = KPS / KB;   // H = 1536: 384 weight registers leave room for one or two k-steps ahead
         frag bb[2][KB][2];
@@ -2096,16 +2107,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       if (*flag) break;
       CAIMAN_PROF2(3)
       if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
+        // the three foreign blocks with three loads issued back to back (sources kq + 1, kq + 2, kq + 3 mod 4), then put in
+        // the order of the K quarters by selects: a load per `src != kq` branch was three serial L2 round trips in the chain
+        const f32x4 own = *reinterpret_cast<const f32x4*>(ownp + eb * 36 + ul4);
+        f32x4 got[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int src = (kq + 1 + i) & 3;
+          const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+          const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (eb * 32 + ul4) * (int)sizeof(float), 0, 16);
+          __builtin_memcpy(&got[i], &raw, 16);
+        }
         f32x4 part[4];
 #pragma unroll
-        for (int src = 0; src < 4; ++src) {
-          if (src == kq) {
-            part[src] = *reinterpret_cast<const f32x4*>(ownp + eb * 36 + ul4);
-          } else {
-            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (eb * 32 + ul4) * (int)sizeof(float), 0, 16);
-            __builtin_memcpy(&part[src], &raw, 16);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int d = (j - kq - 1) & 3;   // 3: this workgroup's own quarter
+#pragma unroll
+          for (int q = 0; q < 4; ++q) part[j][q] = d == 0 ? got[0][q] : (d == 1 ? got[1][q] : (d == 2 ? got[2][q] : own[q]));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
@@ -2283,19 +2301,22 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
     const T* delta = w.delta[slot] - d_st * s;
     T* dG = w.dG[slot] - go * s;
     const bool has_in = s > 0 || has_in0;
+    // the epilogue's operands go BEHIND the DMAs of the gather (see lstm_bwd_resident2): exactly six unconditional loads
     frag gv0, gv1;
     g4 cpv, ccv, dlv;
-    if (ep) {   // none of these depends on the recurrence: they travel while the workgroup waits
-      gv0 = *reinterpret_cast<const frag*>(g + eoff * 4);
-      gv1 = *reinterpret_cast<const frag*>(g + eoff * 4 + 8);
-      cpv = *reinterpret_cast<const g4*>(c_prev + eoff);
-      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoff);
-      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)eb * d_sb + u);
-      const f32x4 dv = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoff);   // written by this thread a timestep ago
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dcs[q] = dv[q];
-    }
+    f32x4 dv;
+    const int ebc = eb < B ? eb : B - 1;
+    const int64_t eoffc = (int64_t)ebc * H + u;
+    auto load_epilogue_operands = [&]() {
+      gv0 = *reinterpret_cast<const frag*>(g + eoffc * 4);
+      gv1 = *reinterpret_cast<const frag*>(g + eoffc * 4 + 8);
+      cpv = *reinterpret_cast<const g4*>(c_prev + eoffc);
+      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoffc);
+      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)ebc * d_sb + u);
+      dv = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoffc);   // written by this thread a timestep ago
+    };
     float psum[4] = {0.f, 0.f, 0.f, 0.f};   // (dG[t+1] R) for this thread's 4 units, all of K
+    if (!has_in) load_epilogue_operands();
     if (has_in) {
       if (s > 0 && tid == 0) {
         const unsigned target = (unsigned)PPQ * (unsigned)s;
@@ -2319,6 +2340,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // issue order pinned: [8 NST DMAs][6 loads] -- the wait counts below depend on it
+      load_epilogue_operands();
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 acc[2][2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -2326,10 +2350,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
         for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NST; ++q) {
-        // this wave's rows of stage q have landed (vmcnt: the later stages' 8 instructions each may still fly) and its
-        // LDS reads of the stage before have returned; behind the bare barrier that holds for every wave
-        if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x0078); __builtin_amdgcn_s_barrier(); }
-        else { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); }
+        // this wave's rows of stage q have landed (vmcnt: the later stage's 8 instructions and the 6 loads may still fly) and
+        // its LDS reads of the stage before have returned; behind the bare barrier that holds for every wave (vmcnt 14 / 6)
+        if (q + 1 < NST) { __builtin_amdgcn_s_waitcnt(0x007E); __builtin_amdgcn_s_barrier(); }
+        else { __builtin_amdgcn_s_waitcnt(0x0076); __builtin_amdgcn_s_barrier(); }
         const T* bq = ring(q);
         constexpr int KB = 4, NB_ = KPS / KB;
         frag bb[2][KB][2];
@@ -2392,22 +2416,31 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
       __syncthreads();
       if (*flag) { aborted = true; break; }
       if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
+        // the three foreign blocks with three loads issued back to back (sources kq + 1, kq + 2, kq + 3 mod 4), then put in
+        // the order of the K quarters by selects: a load per `src != kq` branch was three serial L2 round trips in the chain
+        const f32x4 own = *reinterpret_cast<const f32x4*>(ownp + ebl * 36 + ul4);
+        f32x4 got[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int src = (kq + 1 + i) & 3;
+          const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+          const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (ebl * 32 + ul4) * (int)sizeof(float), 0, 16);
+          __builtin_memcpy(&got[i], &raw, 16);
+        }
         f32x4 part[4];
 #pragma unroll
-        for (int src = 0; src < 4; ++src) {
-          if (src == kq) {
-            part[src] = *reinterpret_cast<const f32x4*>(ownp + ebl * 36 + ul4);
-          } else {
-            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (ebl * 32 + ul4) * (int)sizeof(float), 0, 16);
-            __builtin_memcpy(&part[src], &raw, 16);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int d = (j - kq - 1) & 3;   // 3: this workgroup's own quarter
+#pragma unroll
+          for (int q = 0; q < 4; ++q) part[j][q] = d == 0 ? got[0][q] : (d == 1 ? got[1][q] : (d == 2 ? got[2][q] : own[q]));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
       }
     }
     if (ep) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dcs[q] = dv[q];
       g4 vI, vF, vG, vO;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
