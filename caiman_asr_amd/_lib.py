@@ -221,7 +221,8 @@ def lib():
                 f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "There is no CPU/PyTorch fallback for the RNN-T kernels.")
         try:
-            L = ctypes.CDLL(LIB_PATH)
+            # CAIMAN_LIB_OVERRIDE: a measurement build of the same sources (A/B of compile-time variants on one box)
+            L = ctypes.CDLL(os.environ.get("CAIMAN_LIB_OVERRIDE") or LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise MissingNativeLibrary(f"cannot load {LIB_PATH}: {e}") from e
         for name, (argtypes, restype) in _SIGS.items():

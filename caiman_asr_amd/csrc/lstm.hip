@@ -2107,23 +2107,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       if (*flag) break;
       CAIMAN_PROF2(3)
       if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
-        // the three foreign blocks with three loads issued back to back (sources kq + 1, kq + 2, kq + 3 mod 4), then put in
-        // the order of the K quarters by selects: a load per `src != kq` branch was three serial L2 round trips in the chain
-        const f32x4 own = *reinterpret_cast<const f32x4*>(ownp + eb * 36 + ul4);
-        f32x4 got[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int src = (kq + 1 + i) & 3;
-          const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
-          const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (eb * 32 + ul4) * (int)sizeof(float), 0, 16);
-          __builtin_memcpy(&got[i], &raw, 16);
-        }
+        // (one load per `src != kq` branch, each with its own wait.  Three back-to-back loads from sources kq + 1 .. kq + 3 put
+        // in order by selects looked better in the ISA -- one wait instead of three -- and measured WORSE: backward recurrence
+        // 4.45 -> 4.78 ms per training step in an A/B of four builds on one box, gpurun_out/r3j)
         f32x4 part[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int d = (j - kq - 1) & 3;   // 3: this workgroup's own quarter
-#pragma unroll
-          for (int q = 0; q < 4; ++q) part[j][q] = d == 0 ? got[0][q] : (d == 1 ? got[1][q] : (d == 2 ? got[2][q] : own[q]));
+        for (int src = 0; src < 4; ++src) {
+          if (src == kq) {
+            part[src] = *reinterpret_cast<const f32x4*>(ownp + eb * 36 + ul4);
+          } else {
+            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (eb * 32 + ul4) * (int)sizeof(float), 0, 16);
+            __builtin_memcpy(&part[src], &raw, 16);
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
@@ -2416,23 +2412,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
       __syncthreads();
       if (*flag) { aborted = true; break; }
       if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
-        // the three foreign blocks with three loads issued back to back (sources kq + 1, kq + 2, kq + 3 mod 4), then put in
-        // the order of the K quarters by selects: a load per `src != kq` branch was three serial L2 round trips in the chain
-        const f32x4 own = *reinterpret_cast<const f32x4*>(ownp + ebl * 36 + ul4);
-        f32x4 got[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int src = (kq + 1 + i) & 3;
-          const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
-          const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (ebl * 32 + ul4) * (int)sizeof(float), 0, 16);
-          __builtin_memcpy(&got[i], &raw, 16);
-        }
         f32x4 part[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int d = (j - kq - 1) & 3;   // 3: this workgroup's own quarter
-#pragma unroll
-          for (int q = 0; q < 4; ++q) part[j][q] = d == 0 ? got[0][q] : (d == 1 ? got[1][q] : (d == 2 ? got[2][q] : own[q]));
+        for (int src = 0; src < 4; ++src) {
+          if (src == kq) {
+            part[src] = *reinterpret_cast<const f32x4*>(ownp + ebl * 36 + ul4);
+          } else {
+            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (ebl * 32 + ul4) * (int)sizeof(float), 0, 16);
+            __builtin_memcpy(&part[src], &raw, 16);
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
