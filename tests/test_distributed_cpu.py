@@ -141,6 +141,23 @@ def _worker_protocol(rank, world, port, out):
             raised = "no_sync" in str(e)
         red.finish()
         assert raised
+        # a dropped window (NaN loss: train.py:279-284): buckets may be in flight and parameters marked; reset() drains and
+        # forgets them, and the next window runs as if nothing had happened (round-2 advisor finding)
+        flat_g.zero_()
+        loss_of(data[rank, 0]).mean().backward()          # hooks on: buckets launched, finish() will NOT be called
+        assert any(red._launched) and any(red._ready)
+        red.reset()
+        assert not any(red._launched) and not any(red._ready) and not red._handles and not red._pass_cb_queued
+        flat_g.zero_()
+        with red.no_sync():
+            loss_of(data[rank, 0]).sum().backward()
+        red.mark_ready(params)
+        red.finish()
+        flat_one = flat_g.clone()
+        flat_g.zero_()
+        with red.no_sync():
+            (loss_of(data[0, 0]).sum() + loss_of(data[1, 0]).sum()).mul(0.5).backward()
+        assert torch.allclose(flat_one, flat_g, atol=1e-6)     # the mean over the two ranks' windows, nothing stale in it
         out.put((rank, "ok", float(ref.abs().sum())))
     except Exception:  # pragma: no cover
         import traceback

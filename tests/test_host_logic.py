@@ -292,3 +292,74 @@ def test_optimizer_wrapper_lower_bound_logic():
     plain = OptimizerWrapper(Namespace(no_amp=True), FakeOpt(), None)
     plain.step()
     assert FakeOpt.n == 1
+
+
+def test_fused_decode_weight_images_reproduce_the_concatenated_gemm():
+    """rnnt/streaming_lstm.py::fused_layer_weights (operand images of caiman_lstm_step_gemm): rows ordered [unit][gate],
+    input columns zero-padded to a multiple of 128.  [x | 0 | h] against the image must give the gate pre-activations of
+    [x | h] against [W_ih | W_hh] (training/lib/csrc/lstm.cu:259-271), permuted to [unit][gate]."""
+    from caiman_asr_amd.rnnt.streaming_lstm import fused_layer_weights
+
+    torch.manual_seed(0)
+    I, H, n = 240, 128, 5
+    lstm = torch.nn.LSTM(I, H, 2)
+    for l, (i_in, ip) in enumerate(((I, 256), (H, 128))):
+        W, b, Ip = fused_layer_weights(lstm, l, torch.float32)
+        assert Ip == ip and W.shape == (4 * H, Ip + H) and b.shape == (4 * H,)
+        x, h = torch.randn(n, i_in), torch.randn(n, H)
+        X = torch.zeros(n, Ip + H)
+        X[:, :i_in], X[:, Ip:] = x, h
+        got = X @ W.t() + b                                               # [n, (unit, gate)]
+        ref = (x @ getattr(lstm, f"weight_ih_l{l}").t() + h @ getattr(lstm, f"weight_hh_l{l}").t()
+               + getattr(lstm, f"bias_ih_l{l}") + getattr(lstm, f"bias_hh_l{l}"))   # [n, (gate, unit)]
+        assert torch.allclose(got.view(n, H, 4), ref.view(n, 4, H).transpose(1, 2), atol=1e-5)
+
+
+def test_storage_oracle_rounds_values_forward_and_gradients_backward():
+    """oracle/model.py storage mode: rf rounds the value and passes the gradient, rb passes the value and rounds the gradient;
+    the cell's backward with storage=None is plain autograd of the same formulas; storage=bf16 changes the result by no more
+    than bf16 resolution allows."""
+    from oracle import model as om
+
+    om._STORAGE = torch.bfloat16
+    try:
+        x = torch.tensor([1.0 + 2.0 ** -10, -3.0 - 2.0 ** -9], dtype=torch.float64, requires_grad=True)
+        y = om.rf(x)
+        assert torch.equal(y.detach(), x.detach().to(torch.bfloat16).double()) and not torch.equal(y.detach(), x.detach())
+        g = torch.tensor([1.0 + 2.0 ** -10, 2.0 + 2.0 ** -8], dtype=torch.float64)
+        y.backward(g)
+        assert torch.equal(x.grad, g)
+        x.grad = None
+        z = om.rb(x)
+        assert torch.equal(z.detach(), x.detach())
+        z.backward(g)
+        assert torch.equal(x.grad, g.to(torch.bfloat16).double()) and not torch.equal(x.grad, g)
+    finally:
+        om._STORAGE = None
+    torch.manual_seed(1)
+    z = torch.randn(3, 16, dtype=torch.float64, requires_grad=True)
+    c = torch.randn(3, 4, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda a, b: om._Cell.apply(a, b, None), (z, c))
+    h0, c0 = om._Cell.apply(z, c, None)
+    h1, c1 = om._Cell.apply(z, c, torch.bfloat16)
+    assert torch.equal(h0, h1) and torch.equal(c0, c1)             # forward values are not touched by the storage type
+    g0 = torch.autograd.grad((h0.sum() + c0.sum()), (z, c))
+    g1 = torch.autograd.grad((h1.sum() + c1.sum()), (z, c))
+    for a, b in zip(g0, g1):
+        assert not torch.equal(a, b) and torch.allclose(a, b, atol=3e-2)
+
+
+def test_profile_kernel_names_map_to_their_rows():
+    import importlib.util
+    import os as _os
+
+    spec = importlib.util.spec_from_file_location("profile_summary", _os.path.join(_os.path.dirname(GOLD), "..", "tools", "profile_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    assert ps.short("_ZN6caiman12_GLOBAL__N_124lstm_fwd_resident_bt_dmaIDF16bLb0ELi32EEEvNS0_8FwdSlotsIT_EEiPjS5_S5_") == "lstm_fwd_resident_bt_dma"
+    assert ps.short("_ZN6caiman12_GLOBAL__N_120lstm_fwd_resident_btIDF16bLb0ELi32EEEv") == "lstm_fwd_resident_bt"
+    assert ps.short("_ZN6caiman12_GLOBAL__N_121lstm_fwd_resident_dmaIDF16bLb0ELi48ELb0ELi2EEEv") == "lstm_fwd_resident_dma"
+    assert ps.short("_ZN6caiman12_GLOBAL__N_116proj_gemm_kernelIDF16bLi128ELi128ELi2ELi8ELi1ELb1EEEvNS0_9ProjBatchE") == "proj_gemm_kernel[cell]"
+    assert ps.short("_ZN6caiman12_GLOBAL__N_116proj_gemm_kernelIDF16bLi128ELi128ELi2ELi8ELi1ELb0EEEvNS0_9ProjBatchE") == "proj_gemm_kernel"
+    assert ps.short("Cijk_Ailk_Bjlk_BBS_BH_Bias_HA_S_SAV_UserArgs_MT256x256x32") == "library_gemm"
+    assert ps.short("void at::native::vectorized_elementwise_kernel<4>") is None
