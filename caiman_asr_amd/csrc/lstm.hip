@@ -2504,6 +2504,313 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
   }
 }
 
+// Backward batch tiles with the K quarter of tile-step i + 1 arriving under the MFMAs and the partial exchange of tile-step
+// i (H = 512, 1024; 32 < B <= 128): lstm_bwd_resident2_bt with two buffer sets, the prefetch decision of
+// lstm_fwd_resident_bt_dma (hand-off counter already at its target -> gather now, else the next tile-step waits and gathers
+// as before), a fixed DMA count per tile-step and every wait through the builtin.  A tile-step whose quarter was prefetched
+// starts multiplying at once: no wait for the quarter's producers, no gather in front of the first MFMA.
+template <typename T, bool HARD, int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt_dma(BwdSlots<T> w, int B, unsigned* sync, unsigned* fail_host,
+                                                                float* pws, unsigned* scrub) {
+  constexpr bool PROF = false;
+  using frag = typename frag8<T>::type;
+  using g4 = __attribute__((ext_vector_type(4))) T;
+  constexpr int H = NKS * 32;
+  constexpr int NST = H / 512;                           // LDS-DMA stages of 512 columns (1 KB per batch row)
+  constexpr int LDW = 512 + 8;
+  constexpr int KPS = 16;                                // k-steps per stage
+  constexpr int PPQ = NKS / 4;                           // workgroups that finalise units of one K quarter
+  static_assert(H % 512 == 0 && NST >= 1 && NST <= 2, "2-D split kernel: H = 512 or 1024");
+  __shared__ __attribute__((aligned(16))) T bufE[NST * 32 * LDW], bufO[NST * 32 * LDW];   // two buffer sets, one LDS object each
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ownp = reinterpret_cast<float*>(smem);          // [32 batch][32 units + 4]: this workgroup's own partial block
+  int* flag = reinterpret_cast<int*>(ownp + 32 * 36);    // [0] abort, [1] the next tile-step's K quarter is complete
+
+  int slot, bx;
+  res_role<NKS>(slot, bx);
+  const int nsteps = w.nsteps[slot];
+  res_scrub(scrub, (int)(kResSyncBytesBT / sizeof(unsigned)));
+  if (nsteps <= 0) return;
+  const int kq = bx & 3, jq = bx >> 2;
+  const int ntiles = (B + 31) / 32;
+  unsigned* fail_dev = sync + kMaxSlots * kResMaxTiles * 12 * kResCounterStride;
+  auto counters = [&](int bt) -> unsigned* { return sync + ((slot * kResMaxTiles + bt) * 12) * kResCounterStride; };
+  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kg = lane >> 4;
+
+  // resident fragments: row tiles (16 units) 8 jq + 2 wave + {0, 1}, k-steps kq NKS + [0, NKS)
+  frag wreg[2][NKS];
+  {
+    const T* Rt = w.Rttile[slot];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t blk = (int64_t)jq * 8 + wave * 2 + rt;
+#pragma unroll
+      for (int i = 0; i < NKS; ++i)
+        wreg[rt][i] = *reinterpret_cast<const frag*>(Rt + ((blk * (4 * NKS) + kq * NKS + i) * 16 + r) * 32 + 8 * kg);
+    }
+  }
+  // epilogue role (as in lstm_bwd_resident with j = bx): batch row eb, units u .. u+3
+  const int ebl = tid >> 3, ul4 = (tid & 7) * 4, u = bx * 32 + ul4;   // row within the tile
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[q][e] = 0.f;
+  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+  const float pd = w.drop_p[slot];
+  const float inv_keep = 1.f / (1.f - pd);
+  const int64_t d_st = w.d_st[slot], d_sb = w.d_sb[slot];
+  const int has_in0 = w.has_in0[slot];
+
+  // the K quarter of a dG row block (32 rows x H columns from `src`, rows row_first ..) -> one buffer set
+  auto gather = [&](T* b0, const T* src, int row_first) {
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      T* bq = b0 + q * 32 * LDW;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = wave + 4 * i, bg = row_first + b, bs = bg < B ? bg : B - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (int64_t)bs * 4 * H + q * 512 + lane * 8),
+            (__attribute__((address_space(3))) void*)(bq + b * LDW), 16, 0, 16);
+      }
+    }
+  };
+  int s = 0, bt = 0;
+  bool have = false, aborted = false;   // have: this tile-step's quarter was gathered during the previous tile-step
+  auto body = [&](T* c0, T* n0) {
+    unsigned* ctr = counters(bt);
+    unsigned* qc_wait = ctr + kq * kResCounterStride;
+    unsigned* qc_mine = ctr + ((4 * bx) / NKS) * kResCounterStride;
+    unsigned* gc = ctr + (4 + jq) * kResCounterStride;
+    float* pslot = pws + (size_t)(slot * kResMaxTiles + bt) * kRes2PartialFloatsPerSlot;
+    const int row0 = bt * 32, eb = row0 + ebl;
+    const bool ep = eb < B;
+    const int64_t eoff = (int64_t)eb * H + u;
+    const int bt_n = bt + 1 < ntiles ? bt + 1 : 0, s_n = bt + 1 < ntiles ? s : s + 1;
+    const T* g = w.g[slot] - go * s;
+    const T* c_prev = w.c[slot] - so * s;
+    const T* delta = w.delta[slot] - d_st * s;
+    T* dG = w.dG[slot] - go * s;
+    const bool has_in = s > 0 || has_in0;
+    // the epilogue's operands go BEHIND the DMAs of the gather (see lstm_bwd_resident2): exactly six unconditional loads
+    frag gv0, gv1;
+    g4 cpv, ccv, dlv;
+    f32x4 dv;
+    const int ebc = eb < B ? eb : B - 1;
+    const int64_t eoffc = (int64_t)ebc * H + u;
+    auto load_epilogue_operands = [&]() {
+      gv0 = *reinterpret_cast<const frag*>(g + eoffc * 4);
+      gv1 = *reinterpret_cast<const frag*>(g + eoffc * 4 + 8);
+      cpv = *reinterpret_cast<const g4*>(c_prev + eoffc);
+      ccv = *reinterpret_cast<const g4*>(c_prev + so + eoffc);
+      dlv = *reinterpret_cast<const g4*>(delta + (int64_t)ebc * d_sb + u);
+      dv = *reinterpret_cast<const f32x4*>(w.dC[slot] + eoffc);   // written by this thread a timestep ago
+    };
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};   // (dG[t+1] R) for this thread's 4 units, all of K
+    // (1) this tile-step's K quarter: gathered during the previous tile-step (`have`), or now
+    if (has_in && !have) {
+      if (s > 0 && tid == 0) {
+        if (!res_wait(qc_wait, (unsigned)PPQ * (unsigned)s, fail_dev, fail_host)) flag[0] = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (flag[0]) { aborted = true; return; }
+      gather(c0, dG + go + (int64_t)kq * H, row0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share has landed
+    }
+    // (2) is the NEXT tile-step's quarter complete already?  One relaxed load by one lane, broadcast behind the barrier.
+    const bool next_in = s_n < nsteps && (s_n > 0 || has_in0);
+    if (tid == 0) {
+      int rdy = 0;
+      if (next_in)
+        rdy = s_n == 0 || __hip_atomic_load(counters(bt_n) + kq * kResCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
+                              (unsigned)PPQ * (unsigned)s_n;
+      flag[1] = rdy;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0): visible to the compiler's bookkeeping
+    __builtin_amdgcn_s_barrier();
+    const bool ready = flag[1] != 0;
+    // (3) ALWAYS 8 NST DMA instructions (a gather under a condition makes the wait counts fall back to vmcnt(0) at the join):
+    // the next tile-step's quarter when it is complete, else this step's own dG rows (valid memory, contents irrelevant: the
+    // next tile-step gathers over them after its wait).  They fly under the MFMAs and the partial exchange below.
+    {
+      const T* dG_n = w.dG[slot] - go * s_n;
+      gather(n0, ready ? dG_n + go + (int64_t)kq * H : dG, ready ? bt_n * 32 : row0);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the epilogue's operands behind the DMAs (see lstm_bwd_resident2)
+    load_epilogue_operands();
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_in) {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NST; ++q) {
+        const T* bq = c0 + q * 32 * LDW;
+        constexpr int KB = 4, NB_ = KPS / KB;
+        frag bb[2][KB][2];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          bb[0][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + i * 32 + kg * 8);
+          bb[0][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + i * 32 + kg * 8);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB_; ++nb) {
+          if (nb + 1 < NB_) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+              const int ks = (nb + 1) * KB + i;
+              bb[(nb + 1) & 1][i][0] = *reinterpret_cast<const frag*>(bq + r * LDW + ks * 32 + kg * 8);
+              bb[(nb + 1) & 1][i][1] = *reinterpret_cast<const frag*>(bq + (16 + r) * LDW + ks * 32 + kg * 8);
+            }
+          }
+          // the MFMAs take their operands from this asm: they cannot be hoisted above the reads just issued
+          asm volatile("" : "+v"(bb[nb & 1][0][0]), "+v"(bb[nb & 1][0][1]), "+v"(bb[nb & 1][1][0]), "+v"(bb[nb & 1][1][1]),
+                            "+v"(bb[nb & 1][2][0]), "+v"(bb[nb & 1][2][1]), "+v"(bb[nb & 1][3][0]), "+v"(bb[nb & 1][3][1])
+                       :: "memory");
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int ks = q * KPS + nb * KB + i;
+            acc[0][0] = mfma16(wreg[0][ks], bb[nb & 1][i][0], acc[0][0]);
+            acc[0][1] = mfma16(wreg[0][ks], bb[nb & 1][i][1], acc[0][1]);
+            acc[1][0] = mfma16(wreg[1][ks], bb[nb & 1][i][0], acc[1][0]);
+            acc[1][1] = mfma16(wreg[1][ks], bb[nb & 1][i][1], acc[1][1]);
+          }
+        }
+      }
+      // ---- hand the partial block of columns [128 jq + 32 wave, +32) to the member that finalises them ----------------
+      // C layout: column lane & 15 = batch row of the column tile, row kg * 4 + reg = unit of the row tile
+      const int round = s - (has_in0 ? 0 : 1);
+      float* pround = pslot + ((size_t)(round & 1) * kRes2MaxGroups + jq) * (16 * 1024);
+      if (wave == kq) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            *reinterpret_cast<f32x4*>(ownp + (ct * 16 + r) * 36 + rt * 16 + kg * 4) = acc[rt][ct];
+      } else {
+        const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(wave * 4 + kq) * 1024);   // [dst = wave][src = kq]
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            res_store16(acc[rt][ct], rp, ((ct * 16 + r) * 32 + rt * 16 + kg * 4) * (int)sizeof(float));
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // every storing wave drains before the workgroup signals
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!res_wait(gc, 4u * (unsigned)(round + 1), fail_dev, fail_host)) flag[0] = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __syncthreads();
+      if (flag[0]) { aborted = true; return; }
+      if (ep) {   // the four K-quarter partials of this thread's (batch row, 4 units), added in the order of kq
+        f32x4 part[4];
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {
+          if (src == kq) {
+            part[src] = *reinterpret_cast<const f32x4*>(ownp + ebl * 36 + ul4);
+          } else {
+            const __amdgpu_buffer_rsrc_t rp = res_rsrc(pround + (size_t)(kq * 4 + src) * 1024);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rp, (ebl * 32 + ul4) * (int)sizeof(float), 0, 16);
+            __builtin_memcpy(&part[src], &raw, 16);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) psum[q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+      }
+    }
+    if (ep) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dcs[q] = dv[q];
+      g4 vI, vF, vG, vO;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float dy = static_cast<float>(dlv[q]);
+        if (pd > 0.f) {
+          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
+          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
+        }
+        dy += psum[q];
+        const frag& gv = q < 2 ? gv0 : gv1;
+        const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
+        const float gg = static_cast<float>(gv[(q & 1) * 4 + 2]), go_ = static_cast<float>(gv[(q & 1) * 4 + 3]);
+        const float cp = static_cast<float>(cpv[q]), cc = static_cast<float>(ccv[q]);
+        const float ct = FastAct<HARD>::tanhv(cc);
+        const float dc = dy * go_ * FastAct<HARD>::tanh_prime(ct) + dcs[q];
+        vI[q] = static_cast<T>(dc * gg * FastAct<HARD>::sigm_prime(gi));
+        vF[q] = static_cast<T>(dc * cp * FastAct<HARD>::sigm_prime(gf));
+        vG[q] = static_cast<T>(dc * gi * FastAct<HARD>::tanh_prime(gg));
+        vO[q] = static_cast<T>(dy * ct * FastAct<HARD>::sigm_prime(go_));
+        dcs[q] = dc * gf;
+        bsum[q][0] += static_cast<float>(vI[q]); bsum[q][1] += static_cast<float>(vF[q]);
+        bsum[q][2] += static_cast<float>(vG[q]); bsum[q][3] += static_cast<float>(vO[q]);
+      }
+      frag o0, o1;   // [unit][gate] interleaved: units u, u+1 | u+2, u+3
+      o0[0] = vI[0]; o0[1] = vF[0]; o0[2] = vG[0]; o0[3] = vO[0]; o0[4] = vI[1]; o0[5] = vF[1]; o0[6] = vG[1]; o0[7] = vO[1];
+      o1[0] = vI[2]; o1[1] = vF[2]; o1[2] = vG[2]; o1[3] = vO[2]; o1[4] = vI[3]; o1[5] = vF[3]; o1[6] = vG[3]; o1[7] = vO[3];
+      const __amdgpu_buffer_rsrc_t ro = res_rsrc(dG);
+      res_store16(o0, ro, (int)(eoff * 4) * (int)sizeof(T));
+      res_store16(o1, ro, (int)(eoff * 4 + 8) * (int)sizeof(T));
+      if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
+        const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+        T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4, 4 * NKS)) = o0;
+        *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4 + 8, 4 * NKS)) = o1;
+      }
+      f32x4 dv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dv[q] = dcs[q];
+      *reinterpret_cast<f32x4*>(w.dC[slot] + eoff) = dv;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(qc_mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    have = ready;
+    bt = bt_n;
+    s = s_n;
+  };
+  const int total = nsteps * ntiles;
+  for (int i = 0; i < total && !aborted; i += 2) {
+    body(bufE, bufO);
+    if (i + 1 < total && !aborted) body(bufO, bufE);
+  }
+  if (w.dbias[slot] && !flag[0]) {   // as in lstm_bwd_resident: rows wave * 8 + lane / 8 hold the same units
+    float* red = ownp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bsum[q][e];
+        v += __shfl_xor(v, 8, kWave);
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        bsum[q][e] = v;
+      }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave * 8 + lane) * 16 + q * 4 + e] = bsum[q][e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int cg = tid >> 4, el = tid & 15;
+      const float v = red[(0 * 8 + cg) * 16 + el] + red[(1 * 8 + cg) * 16 + el] + red[(2 * 8 + cg) * 16 + el] +
+                      red[(3 * 8 + cg) * 16 + el];
+      w.dbias[slot][(int64_t)(bx * 32) * 4 + tid] += v;
+    }
+  }
+}
+
 
 
 
@@ -2967,10 +3274,14 @@ bool try_bwd_resident2_bt(const BwdSlots<T>& w, int n_slots, int n_launches, int
   unsigned* sync = res_begin_bt(st, s, &scrub);
   const dim3 grid = res_grid(nks, n_slots, st->cus);
   const size_t lds = (size_t)(32 * 36) * sizeof(float) + 16;
-  if (nks == 16)
-    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
-  else
-    hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
+  const bool dma = g_res_bt_dma.load(std::memory_order_relaxed) != 0;   // double-buffered gather (default) | round-2 kernel
+  if (nks == 16) {
+    if (dma) hipLaunchKernelGGL((lstm_bwd_resident2_bt_dma<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
+    else hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 16>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
+  } else {
+    if (dma) hipLaunchKernelGGL((lstm_bwd_resident2_bt_dma<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
+    else hipLaunchKernelGGL((lstm_bwd_resident2_bt<T, HARD, 32>), grid, dim3(256), lds, s, w, (int)B, sync, st->fail_host, st->partials_bt, scrub);
+  }
   res_end(st, s);
   *err = check_launch("lstm resident backward (2-D split, batch tiles)");
   return true;
@@ -3129,8 +3440,8 @@ extern "C" int caiman_lstm_resident_xcd_roles(int on) { return caiman::g_res_xcd
 
 extern "C" int caiman_lstm_resident_bwd_split(int on) { return caiman::g_res_bwd_split.exchange(on ? 1 : 0); }
 
-// Batch-tile forward kernel: 1 = operands of the next tile-step by LDS-DMA under the MFMAs of the current one (default),
-// 0 = the register-staged kernel of round 2.  Returns the previous setting.  Results are bit-identical.
+// Batch-tile kernels (forward AND backward): 1 = operands of the next tile-step by LDS-DMA under the MFMAs of the current one (default),
+// 0 = the round-2 kernels.  Returns the previous setting.  Results are bit-identical.
 extern "C" int caiman_lstm_resident_bt_dma(int on) { return caiman::g_res_bt_dma.exchange(on ? 1 : 0); }
 
 // Mode 2 phase timers of the 2-D split backward kernel (workgroup 0 of slot 0), 10 ns ticks summed over timesteps:

@@ -218,8 +218,8 @@ int caiman_lstm_resident_mode(int mode);
  * for one quarter of K and gathers a quarter of the dG row; the four K-quarter partial sums meet in a second hand-off
  * per timestep), 0 = the whole-row kernel.  Returns the previous setting. */
 int caiman_lstm_resident_bwd_split(int on);
-/* Batch-tile forward kernel (32 < B <= 128, H = 512 / 1024): 1 (default) = every operand of tile-step i + 1 arrives by
- * LDS-DMA under the MFMAs of tile-step i (two buffer sets), 0 = the register-staged kernel.  Bit-identical results.
+/* Batch-tile kernels (32 < B <= 128, H = 512 / 1024), forward and backward: 1 (default) = the operands of tile-step i + 1
+ * arrive by LDS-DMA under the MFMAs of tile-step i (two buffer sets), 0 = the round-2 kernels.  Bit-identical results.
  * Returns the previous setting. */
 int caiman_lstm_resident_bt_dma(int on);
 /* Mode 2 phase timers of the 2-D split kernel: out8[0..5] = 10 ns ticks {wait for the quarter's producers, gather +
