@@ -107,9 +107,10 @@ def test_model_step_with_the_handwritten_joint_projection_equals_the_library_pat
     yl = torch.tensor([5, 3, 4, 5, 1, 2])
     meta = get_packing_meta_data(xl, yl, 2, device=DEV)
     loss_fn = ApexTransducerLoss(blank_idx=V - 1, eos_idx=None, star_idx=None, packed_input=True)
-    taken = []
-    real_take = tl.take_row_lse
+    taken, bias_sums = [], []
+    real_take, real_bias = tl.take_row_lse, tl.take_bias_gradient
     monkeypatch.setattr(tl, "take_row_lse", lambda t: (taken.append(real_take(t)), taken[-1])[1])
+    monkeypatch.setattr(tl, "take_bias_gradient", lambda t: (bias_sums.append(real_bias(t)), bias_sums[-1])[1])
     out = []
     for mode in ("1", "0"):
         monkeypatch.setattr(overlap, "JOINT_GEMM", mode)
@@ -120,6 +121,9 @@ def test_model_step_with_the_handwritten_joint_projection_equals_the_library_pat
         loss.backward()
         out.append((float(loss), {n: p.grad.float().clone() for n, p in m.named_parameters()}))
     assert taken[0] is not None and taken[1] is None      # hand-written path: normalisers from the GEMM; library path: none offered
+    # the loss backward's fused column sums reach the projection's bias gradient in both modes (the hand-over checks storage,
+    # shape, dtype and the version counter of the gradient tensor: a miss would silently cost a 5 GB pass per step)
+    assert len(bias_sums) == 2 and all(b is not None for b in bias_sums)
     (l1, g1), (l0, g0) = out
     assert abs(l1 - l0) <= 2e-3 * abs(l0), (l1, l0)
     for n in g0:
