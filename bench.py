@@ -39,7 +39,7 @@ import torch.distributed as dist
 FRAME_SECONDS = 0.03  # 10 ms hop x 3 frame subsampling (training/caiman_asr_train/utils/frame_width.py)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
-PMC_FILE = "r02_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
+PMC_FILE = "r03_base_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 BASE_RNNT = dict(  # training/configs/base-8703sp.yaml:73-94
@@ -566,7 +566,8 @@ def main():
                     out["roofline"]["from_profiles"] = {"source": f"profiles/{PMC_FILE} (builder-run rocprofv3 --pmc / --kernel-trace "
                                                                   "passes, NOT measured in this run)",
                                                         "traffic_bytes_per_launch": pmc[kname]["traffic_bytes_per_launch"],
-                                                        "rocprof_kernel_avg_us": pmc[kname].get("rocprof_kernel_avg_us")}
+                                                        "rocprof_kernel_avg_us": pmc[kname].get("kernel_avg_us", pmc[kname].get("rocprof_kernel_avg_us")),
+                                                        "same_launch_population": pmc[kname].get("same_population")}
                 except Exception:
                     pass
             if "loss_bwd" in summ:
