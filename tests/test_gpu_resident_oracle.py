@@ -274,3 +274,37 @@ def test_double_buffered_batch_tile_forward_kernel_is_bit_identical_to_the_regis
     for other in outs[1:]:
         for name, a, b in zip(("gates", "c", "y", "dG", "dbias"), outs[0], other):
             assert torch.equal(a, b), name
+
+
+def test_resident_launches_next_to_a_busy_side_stream_complete_and_agree():
+    """A REAL contended launch (round-2 verdict: the time-out path was only ever tested by injecting a failure count): while
+    a side stream keeps the chip busy with long GEMMs and short kernels, resident launches on the main stream find part of
+    the CUs taken -- the workgroups already placed spin on their peers until the other kernel's workgroups retire (a
+    resident workgroup fills a CU's register file, so the two never share a CU).  The launches must complete without a
+    hand-off time-out and reproduce the uncontended results bit for bit, for the single-tile and the batch-tile kernels."""
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    small = torch.randn(1 << 16, device=DEV)
+    for T, B, H in ((24, 32, 1024), (10, 96, 512)):
+        g = torch.Generator().manual_seed(T + B + H)
+        dt = torch.bfloat16
+        R = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dt)
+        gates = torch.randn(T, B, 4 * H, generator=g).to(dt)
+        c0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+        y0 = (torch.randn(B, H, generator=g) * 0.5).to(dt)
+        delta = torch.randn(T, B, H, generator=g).to(dt)
+        quiet = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    a @ a                      # ~1 ms each: every CU busy when the resident launch arrives
+                    small.add_(1.0)
+            busy = _resident_fwd_bwd(R, gates, c0, y0, delta, False)
+            side.synchronize()
+            for name, x, y in zip(("gates", "c", "y", "dG", "dbias"), quiet, busy):
+                assert torch.equal(x, y), (T, B, H, rep, name)
+    assert lib.caiman_lstm_resident_failures() == 0
