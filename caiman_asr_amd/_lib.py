@@ -23,7 +23,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 # per-file flags.  proj_gemm.hip: keep the MFMA accumulators in VGPRs -- left to itself the register allocator splits
 # the 128 accumulator registers of the 256 x 128 tile between VGPRs and AGPRs and moves ~150 of them per K step
-FILE_FLAGS = {"proj_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "joint_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FILE_FLAGS = {"proj_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "joint_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+              "joint_wgrad.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 class MissingNativeLibrary(RuntimeError):
@@ -148,6 +149,8 @@ _SIGS = {
     "caiman_joint_fc_workspace_elems": ([I64, I64], ctypes.c_int64),
     "caiman_joint_fc_supported": ([I64, I64, I64, I32], ctypes.c_int),
     "caiman_joint_fc_forward": ([P, P, P, P, P, P, I64, I64, I64, I32, P], ctypes.c_int),
+    "caiman_joint_fc_wgrad_plan": ([I64, I64, I64, I32, P], ctypes.c_int),
+    "caiman_joint_fc_wgrad": ([P, P, P, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_proj_gemm": ([P, I32, I32, I32, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_lstm_workspace_elems": ([I64, I64, I32], ctypes.c_int64),

@@ -1,0 +1,244 @@
+// Weight gradient of the joint projection as a hand-written MFMA GEMM (backward).
+//
+// Reference: autograd of `self.joint_fc(h)` = torch.nn.Linear(joint_n_hid, n_classes)
+// (training/caiman_asr_train/rnnt/model.py:409-439): dW = dY^T . h with dY [M, N] the gradient of the packed logits
+// (M = 304 000 lattice cells at LibriSpeech shapes, N = 8704) and h [M, K] the joint activations (K = 768).  The
+// reduction runs over M, the SLOW dimension of both operands: for the matrix cores every fragment is a transposed read.
+// hipBLASLt serves it at 0.92 PF/s (4.4 ms per training step; as 16 row chunks in one batched call, train_utils/overlap.py).
+//
+//   dW[n][k] = sum_m dY[m][n] * h[m][k]        bf16 / f16 operands, fp32 accumulation, fp32 output slabs
+//
+// Geometry: csrc/joint_gemm.hip's -- 256 x 256 output tile per workgroup, 8 waves (2 along n x 4 along k), wave tile
+// 128 x 64, the reduction walked in steps of 32 rows of m through a ring of four LDS stages filled by LDS-DMA with three
+// stages in flight (one counted vmcnt + one bare barrier per step) -- with two differences:
+//  * a stage holds 32 ROWS OF m of both operands as they lie in memory ([32][256] elements, 512-byte rows), and the MFMA
+//    fragments (16 n or k columns x 32 m) are read with `ds_read_b64_tr_b16` (gfx950's transposing LDS read: a group of 16
+//    lanes reads a block of 4 rows x 16 columns and every lane receives one column, guide T10): two reads per fragment.
+//    The 32-byte granules of a row are XOR-swizzled on the DMA source with x(row) = (row & 7) ^ (((row >> 3) & 1) << 2), so
+//    that the two 4-row blocks a 32-lane half reads at a time (rows r .. r+3 and r+8 .. r+11) cover all eight granules of a
+//    256-byte bank window.
+//  * the output tile is tiny and the reduction is long, so M is split: grid = (N/256) * (K/256) tiles x S slices of M, each
+//    workgroup writes its fp32 partial tile into slab s; the caller adds the S slabs (and the < 128 S rows the slices do not
+//    cover) in a fixed order.  A workgroup's loop is M / (32 S) steps long (~1 900): no prologue / epilogue to speak of.
+// The three k-tiles that share a dY panel are consecutive workgroups (same XCD after the remap), so the 5.3 GB of dY cross
+// HBM once.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace caiman {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+template <typename T>
+struct wfrag {
+  using type = __attribute__((ext_vector_type(8))) T;
+};
+__device__ __forceinline__ f32x4 wmfma(wfrag<bf16_t>::type a, wfrag<bf16_t>::type b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 wmfma(wfrag<f16_t>::type a, wfrag<f16_t>::type b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// transposing read: lane 4q + p of a 16-lane group supplies the address of row q, columns 4p .. 4p+3 of a 4 x 16 block;
+// lane i of the group receives column i, row q in element q
+// The address is formed on the stage's own LDS array (array + byte offset): the compiler then knows which stage a read
+// touches and does not wait for the LDS-DMA in flight into the other stages.
+__device__ __forceinline__ bf16x4 tr_read(const bf16_t* stage, unsigned byte) {
+  const auto* p = (const __attribute__((address_space(3))) char*)stage + byte;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ f16x4 tr_read(const f16_t* stage, unsigned byte) {
+  using s16x4 = __attribute__((__vector_size__(4 * sizeof(short)))) short;
+  const auto* p = (const __attribute__((address_space(3))) char*)stage + byte;
+  const s16x4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  f16x4 v;
+  __builtin_memcpy(&v, &raw, 8);
+  return v;
+}
+
+constexpr int WBN = 256, WBK = 256, WBM = 32, WNW = 8;   // tile: 256 n x 256 k, 32 rows of m per stage
+constexpr int WTN = 8, WTK = 4;                            // 16 x 16 blocks of a wave tile: 128 n, 64 k
+constexpr int WROW = 256;                                  // elements per LDS row of a stage (both operands)
+
+template <typename T>
+__global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Hm,
+                                                                 float* __restrict__ slabs, int N, int K, int rows_per_slice,
+                                                                 int tiles_k, int n_tiles) {
+  using frag = typename wfrag<T>::type;
+  __shared__ __attribute__((aligned(1024))) T sA0[WBM * WROW], sA1[WBM * WROW], sA2[WBM * WROW], sA3[WBM * WROW];   // dY rows
+  __shared__ __attribute__((aligned(1024))) T sB0[WBM * WROW], sB1[WBM * WROW], sB2[WBM * WROW], sB3[WBM * WROW];   // h rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // t -> (slice of M, n-tile, k-tile): k-tile fastest, so the workgroups that share a dY panel are neighbours
+  const int slice = t / n_tiles, tt = t - slice * n_tiles;
+  const int n0 = (tt / tiles_k) * WBN, k0 = (tt % tiles_k) * WBK;
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
+
+  // DMA sources: a stage = 32 rows x 512 B per operand = 16 instructions of 2 rows; wave w brings instructions w and w + 8.
+  // Lane l writes the 16-byte piece at (row l >> 5, position l & 31) and fetches the piece that belongs there: granule
+  // (position >> 1) ^ x(row), same half.
+  unsigned a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + WNW * i) * 2 + (lane >> 5), pos = lane & 31;
+    const int x = (row & 7) ^ (((row >> 3) & 1) << 2);
+    const int src_piece = (((pos >> 1) ^ x) << 1) | (pos & 1);
+    a_off[i] = (unsigned)((row * N + src_piece * 8) * (int)sizeof(T));
+    b_off[i] = (unsigned)((row * K + src_piece * 8) * (int)sizeof(T));
+  }
+  const char* a_base = reinterpret_cast<const char*>(dY + m_begin * N + n0);
+  const char* b_base = reinterpret_cast<const char*>(Hm + m_begin * K + k0);
+  const int64_t a_step = (int64_t)WBM * N * (int64_t)sizeof(T), b_step = (int64_t)WBM * K * (int64_t)sizeof(T);
+
+  auto issue = [&](T* lA, T* lB, int s) {
+    const char* ab = a_base + (int64_t)s * a_step;
+    const char* bb = b_base + (int64_t)s * b_step;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(lA + (wave + WNW * i) * 2 * WROW), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bb + b_off[i]),
+                                       (__attribute__((address_space(3))) void*)(lB + (wave + WNW * i) * 2 * WROW), 16, 0, 0);
+  };
+
+  const int wr = wave >> 2, wc = wave & 3;        // wave tile: n [128 wr, +128), k [64 wc, +64)
+  const int kq = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  // transposed-read addresses (bytes inside a stage): block rows 8 kq + 4 h + q4 (h = 0, 1), columns 16 c + 4 p4.  Column
+  // block c is granule c of the row, stored at granule c ^ x(row); bits 5..8 of a row's byte offset hold nothing else,
+  // so address(c, h) = base[h] ^ (c << 5) with x folded into the base: one v_xor with a constant per read.
+  unsigned baseA[2], baseB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * kq + 4 * h + q4;
+    const int x = (row & 7) ^ (((row >> 3) & 1) << 2);
+    const unsigned b0 = (unsigned)(row * WROW * (int)sizeof(T) + p4 * 8 + (x << 5));
+    baseA[h] = b0 ^ (unsigned)(wr << 8);   // c = 8 wr + a
+    baseB[h] = b0 ^ (unsigned)(wc << 7);   // c = 4 wc + b
+  }
+  f32x4 acc[WTN][WTK];
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const T* lA, const T* lB) {
+    frag bf[WTK], af[2];
+    // the 24 read addresses are two instructions away from these four registers; keeping them opaque per step stops the
+    // compiler from hoisting 24 x 4 stage addresses out of the loop (and spilling them)
+    asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseB[0]), "+v"(baseB[1]));
+    auto read_a = [&](int a, frag& f) {
+      const auto lo = tr_read(lA, baseA[0] ^ (unsigned)(a << 5));
+      const auto hi = tr_read(lA, baseA[1] ^ (unsigned)(a << 5));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    };
+#pragma unroll
+    for (int b = 0; b < WTK; ++b) {
+      const auto lo = tr_read(lB, baseB[0] ^ (unsigned)(b << 5));
+      const auto hi = tr_read(lB, baseB[1] ^ (unsigned)(b << 5));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bf[b][e] = lo[e]; bf[b][4 + e] = hi[e]; }
+    }
+    read_a(0, af[0]);
+#pragma unroll
+    for (int a = 0; a < WTN; ++a) {
+      if (a + 1 < WTN) read_a(a + 1, af[(a + 1) & 1]);     // one fragment ahead of the MFMAs that consume af[a & 1]
+#pragma unroll
+      for (int b = 0; b < WTK; ++b) acc[a][b] = wmfma(af[a & 1], bf[b], acc[a][b]);
+    }
+  };
+
+  auto steady = [&](const T* cA, const T* cB, T* nA, T* nB, int s) {
+    __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): stages s + 1, s + 2 may still fly
+    __builtin_amdgcn_s_barrier();
+    issue(nA, nB, s + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cA, cB);
+  };
+  const int nk = rows_per_slice / WBM;    // a multiple of four, at least four
+  issue(sA0, sB0, 0);
+  issue(sA1, sB1, 1);
+  issue(sA2, sB2, 2);
+  int s = 0;
+  for (; s + 4 <= nk - 3; s += 4) {
+    steady(sA0, sB0, sA3, sB3, s);
+    steady(sA1, sB1, sA0, sB0, s + 1);
+    steady(sA2, sB2, sA1, sB1, s + 2);
+    steady(sA3, sB3, sA2, sB2, s + 3);
+  }
+  steady(sA0, sB0, sA3, sB3, s);
+  __builtin_amdgcn_s_waitcnt(0x0078);
+  __builtin_amdgcn_s_barrier();
+  compute(sA1, sB1);
+  __builtin_amdgcn_s_waitcnt(0x0074);
+  __builtin_amdgcn_s_barrier();
+  compute(sA2, sB2);
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+  compute(sA3, sB3);
+
+  // epilogue: D[i][j] of a block sits in lane (j = lane & 15, i = 4 (lane >> 4) + reg): rows = n (A operand), columns = k
+  float* out = slabs + ((int64_t)slice * N + n0 + wr * 128) * K + k0 + wc * 64;
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTK; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[(int64_t)(a * 16 + kq * 4 + e) * K + b * 16 + li] = acc[a][b][e];
+}
+
+}  // namespace
+}  // namespace caiman
+
+// Slices of M the kernel wants for a [M, N] x [M, K] product on this chip (>= 1), and the rows it then covers:
+// rows_covered = slices * rows_per_slice with rows_per_slice a multiple of 128; 0 slices: shape not supported.
+extern "C" int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice) {
+  if (!(dtype == CAIMAN_BF16 || dtype == CAIMAN_F16) || N < 256 || N % 256 || K < 256 || K % 256 || M < 512) return 0;
+  if (N * 2 * 32 >= ((int64_t)1 << 31) || M * N >= ((int64_t)1 << 46)) return 0;
+  const int64_t tiles = (N / 256) * (K / 256);
+  static const int env_s = std::getenv("CAIMAN_WGRAD_SLICES") ? std::atoi(std::getenv("CAIMAN_WGRAD_SLICES")) : 0;
+  // one workgroup per CU (128 KB of LDS): the largest slice count that still fits two full rounds of the 256 CUs
+  int64_t s = env_s > 0 ? env_s : std::max<int64_t>(1, (2 * 256) / tiles);
+  while (s > 1 && M / (128 * s) < 1) --s;
+  const int64_t per = M / (128 * s) * 128;
+  if (per < 128) return 0;
+  if (rows_per_slice) *rows_per_slice = per;
+  return (int)s;
+}
+
+// slabs [slices][N][K] fp32 (written, not accumulated): slab s = sum over rows [s * rows_per_slice, +rows_per_slice) of
+// dY[m][n] * h[m][k].  Rows from slices * rows_per_slice on are the caller's.
+extern "C" int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
+                                     int64_t rows_per_slice, int dtype, caiman_stream_t stream) {
+  using namespace caiman;
+  int64_t per = 0;
+  CAIMAN_CHECK(caiman_joint_fc_wgrad_plan(M, N, K, dtype, &per) > 0, "joint_fc_wgrad: bf16 / f16, N, K %% 256 == 0, M >= 512");
+  CAIMAN_CHECK(slices >= 1 && rows_per_slice >= 128 && rows_per_slice % 128 == 0 && (int64_t)slices * rows_per_slice <= M,
+               "joint_fc_wgrad: slices x rows_per_slice must be multiples of 128 rows inside M");
+  CAIMAN_CHECK(dY && H && slabs, "joint_fc_wgrad: null pointer");
+  auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+  CAIMAN_CHECK(al(dY, 16) && al(H, 16) && al(slabs, 16), "joint_fc_wgrad: 16-byte aligned operands");
+  const int tiles_k = (int)(K / WBK), n_tiles = (int)(N / WBN) * tiles_k;
+  const int64_t grid = (int64_t)n_tiles * slices;
+  CAIMAN_CHECK(grid < ((int64_t)1 << 31), "joint_fc_wgrad: too many tiles");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == CAIMAN_BF16)
+    hipLaunchKernelGGL((joint_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const bf16_t*)dY, (const bf16_t*)H,
+                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles);
+  else
+    hipLaunchKernelGGL((joint_wgrad_kernel<f16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const f16_t*)dY, (const f16_t*)H,
+                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles);
+  return check_launch("joint projection weight gradient");
+}

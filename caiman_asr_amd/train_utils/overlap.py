@@ -70,6 +70,10 @@ def _weight_gradient(dy2, x2):
     S = WGRAD_SPLIT
     if not dy2.is_cuda or dy2.dtype not in (torch.float16, torch.bfloat16) or rows < 4096 * S:
         return torch.mm(dy2.t(), x2)
+    if JOINT_WGRAD and dy2.is_contiguous() and x2.is_contiguous() and x2.dtype == dy2.dtype:
+        out = _joint_wgrad(dy2, x2)
+        if out is not None:
+            return out
     per = rows // S
     main = per * S
     a = dy2[:main].view(S, per, dy2.shape[1])
@@ -107,6 +111,33 @@ def _joint_gemm(a2, w, bias, want_lse):
                                            None if lse is None else _lib.ptr(lse), None if ws is None else _lib.ptr(ws),
                                            M, N, K, tag, _lib.stream()))
     return c, lse
+
+
+# The projection's weight gradient on the hand-written transposed-read GEMM (csrc/joint_wgrad.hip).  CAIMAN_JOINT_WGRAD=1 | 0.
+JOINT_WGRAD = __import__("os").environ.get("CAIMAN_JOINT_WGRAD", "0") != "0"
+
+
+def _joint_wgrad(dy2, x2):
+    """dy2 [M, N]^T . x2 [M, K] -> [N, K] fp32 through caiman_joint_fc_wgrad (slices of M into fp32 slabs, added in order,
+    plus the library product of the few rows the slices do not cover), or None when the shape is outside the kernel."""
+    import ctypes
+
+    from caiman_asr_amd import _lib
+
+    M, N = dy2.shape
+    K = x2.shape[1]
+    lib, tag = _lib.lib(), _lib.dtype_tag(dy2.dtype)
+    per = ctypes.c_int64(0)
+    slices = lib.caiman_joint_fc_wgrad_plan(M, N, K, tag, ctypes.byref(per))
+    if slices <= 0:
+        return None
+    slabs = torch.empty((slices, N, K), dtype=torch.float32, device=dy2.device)
+    _lib.check(lib.caiman_joint_fc_wgrad(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(slabs), M, N, K, slices, per.value, tag, _lib.stream()))
+    dw = slabs.sum(0)
+    done = slices * per.value
+    if done < M:
+        dw += torch.mm(dy2[done:].t(), x2[done:], out_dtype=torch.float32)
+    return dw
 
 
 class _LinearTransposedBackward(torch.autograd.Function):

@@ -333,6 +333,14 @@ int64_t caiman_joint_fc_workspace_elems(int64_t M, int64_t N);
 int caiman_joint_fc_supported(int64_t M, int64_t N, int64_t K, int dtype);
 int caiman_joint_fc_forward(const void* A, const void* W, const void* bias, void* C, float* lse, float* workspace,
                             int64_t M, int64_t N, int64_t K, int dtype, caiman_stream_t stream);
+/* Weight gradient of the same projection (csrc/joint_wgrad.hip) — replaces autograd's dW = dY^T . h of torch.nn.Linear
+ * (training/caiman_asr_train/rnnt/model.py:409-439): dY [M, N], H [M, K] in `dtype`, the reduction over M split into
+ * `slices` consecutive row ranges of `rows_per_slice` rows (caiman_joint_fc_wgrad_plan chooses both; 0 = shape not
+ * supported: N, K % 256 == 0, bf16 / f16); slabs [slices][N][K] fp32 receives one partial product per slice (written, not
+ * accumulated).  The caller adds the slabs in order, plus the product of the rows past slices * rows_per_slice. */
+int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice);
+int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
+                          int64_t rows_per_slice, int dtype, caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not

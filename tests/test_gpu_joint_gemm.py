@@ -129,3 +129,67 @@ def test_model_step_with_the_handwritten_joint_projection_equals_the_library_pat
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-12
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-2 * scale, n
+
+
+# ---- weight gradient: dW = dY^T . h on the transposed-read kernel (csrc/joint_wgrad.hip) ----------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [
+    (512, 256, 256),          # one tile, the shortest slice (4 stages of 32 rows per slice at most)
+    (5000, 512, 768),         # rows past the slices (5000 is not a multiple of 128): the caller's remainder product
+    (20011, 8704, 768),       # the joint projection's own N and K: 102 tiles x 5 slices
+    (9000, 2048, 1024),       # K = 1024 (large-196M joint_n_hid)
+])
+def test_joint_fc_wgrad_matches_fp32_product(dtype, M, N, K):
+    """fp32 accumulation of 16-bit operands; the result is fp32, so what differs from the fp32 reference product is the
+    order of M additions: |err| <= 1e-5 * sqrt(M) * the operands' scale (measured 3e-6 relative to the result's range)."""
+    from caiman_asr_amd.train_utils.overlap import _joint_wgrad
+
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(dtype)
+    h = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    h[:, 3] = 0.0                                   # asymmetric content: a swapped n / k would not pass
+    dy[:, 5] *= 4.0
+    dw = _joint_wgrad(dy, h)
+    assert dw is not None, "shape rejected by caiman_joint_fc_wgrad_plan"
+    torch.cuda.synchronize()
+    assert dw.dtype == torch.float32 and dw.shape == (N, K)
+    ref = torch.zeros(N, K, device=DEV, dtype=torch.float64)
+    for m0 in range(0, M, 4096):
+        ref += dy[m0:m0 + 4096].double().t() @ h[m0:m0 + 4096].double()
+    err = (dw.double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert (dw[:, 3] == 0).all()
+
+
+def test_joint_fc_wgrad_is_deterministic_over_repeated_launches():
+    """Race screen for the ring (see the forward's): 8 launches at training width, bit-identical slabs."""
+    from caiman_asr_amd.train_utils.overlap import _joint_wgrad
+
+    M, N, K = 60800, 8704, 768
+    g = torch.Generator(device=DEV).manual_seed(11)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    h = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    first = _joint_wgrad(dy, h)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=DEV)
+    for i in range(8):
+        if i % 2:
+            with torch.cuda.stream(side):
+                junk @ junk
+        again = _joint_wgrad(dy, h)
+        assert torch.equal(first, again), i
+    torch.cuda.synchronize()
+
+
+def test_joint_fc_wgrad_plan_rejects_what_the_kernel_cannot_take():
+    import ctypes
+
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    per = ctypes.c_int64(0)
+    assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 768, _lib.dtype_tag(torch.bfloat16), ctypes.byref(per)) == 5
+    assert per.value == 60800
+    assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 700, _lib.dtype_tag(torch.bfloat16), ctypes.byref(per)) == 0
+    assert lib.caiman_joint_fc_wgrad_plan(100, 512, 512, _lib.dtype_tag(torch.bfloat16), ctypes.byref(per)) == 0
+    assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 768, _lib.dtype_tag(torch.float32), ctypes.byref(per)) == 0

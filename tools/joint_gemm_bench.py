@@ -12,7 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from caiman_asr_amd.rnnt_ext.cuda.logsumexp import logsumexp  # noqa: E402
-from caiman_asr_amd.train_utils.overlap import _joint_gemm  # noqa: E402
+from caiman_asr_amd.train_utils.overlap import _joint_gemm, _joint_wgrad, _weight_gradient  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=304000)
@@ -46,13 +46,15 @@ def lib_fwd():
 
 
 res = {"rows": M, "K": K, "N": N, "tflop": 2.0 * M * N * K / 1e12}
-rows = {k: [] for k in ("hand_fwd_lse", "lib_fwd", "lib_fwd_lse", "hand_dx", "lib_dx")}
+rows = {k: [] for k in ("hand_fwd_lse", "lib_fwd", "lib_fwd_lse", "hand_dx", "lib_dx", "hand_dw", "lib_dw")}
 for _ in range(args.rounds):
     rows["hand_fwd_lse"].append(timed(lambda: _joint_gemm(a, w, b, True)))
     rows["lib_fwd"].append(timed(lambda: torch.nn.functional.linear(a, w, b)))
     rows["lib_fwd_lse"].append(timed(lib_fwd))
     rows["hand_dx"].append(timed(lambda: _joint_gemm(dy, wt, None, False)))
     rows["lib_dx"].append(timed(lambda: torch.mm(dy, wt.t())))
+    rows["hand_dw"].append(timed(lambda: _joint_wgrad(dy, a)))
+    rows["lib_dw"].append(timed(lambda: _weight_gradient(dy, a)))
 for k, v in rows.items():
     med = sorted(v)[len(v) // 2]
     res[k] = {"ms_median": round(med, 3), "ms_min": round(min(v), 3), "pflops_median": round(res["tflop"] / med, 3)}
@@ -60,4 +62,6 @@ c1, l1 = _joint_gemm(a, w, b, True)
 c0, l0 = lib_fwd()
 res["max_abs_diff_logits"] = float((c1.float() - c0.float()).abs().max())
 res["max_abs_diff_lse"] = float((l1 - l0).abs().max())
+dw1, dw0 = _joint_wgrad(dy, a), _weight_gradient(dy, a).float()
+res["max_abs_diff_dw_rel"] = float((dw1 - dw0).abs().max() / dw0.abs().max())
 print(json.dumps(res))
