@@ -209,8 +209,20 @@ extern "C" int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int d
   if (N * 2 * 32 >= ((int64_t)1 << 31) || M * N >= ((int64_t)1 << 46)) return 0;
   const int64_t tiles = (N / 256) * (K / 256);
   static const int env_s = std::getenv("CAIMAN_WGRAD_SLICES") ? std::atoi(std::getenv("CAIMAN_WGRAD_SLICES")) : 0;
-  // one workgroup per CU (128 KB of LDS): the largest slice count that still fits two full rounds of the 256 CUs
-  int64_t s = env_s > 0 ? env_s : std::max<int64_t>(1, (2 * 256) / tiles);
+  // One workgroup per CU (128 KB of LDS), so the grid runs in rounds of 256 workgroups and a slice count is as good as its
+  // last round is full: time(s) = rounds(s) x steps per slice x 0.86 us (measured step of 32 rows) + s slabs written
+  // and read back at ~5 TB/s.  8704 x 768: 102 tiles -> 5 slices (510 workgroups, 2 rounds); 17408 x 1024: 272 tiles ->
+  // 16 slices (4352 workgroups, 17 rounds) -- one slice would leave the second round 6 % full.
+  constexpr int64_t kCus = 256;
+  int64_t s = 1;
+  double best = 1e30;
+  for (int64_t c = 1; c <= 32 && M / (128 * c) >= 4; ++c) {
+    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (128 * c) * 4, rest = M - c * steps * 32;
+    const double t = (double)rounds * (double)steps * 0.86e-6 + (double)c * (double)(N * K) * 8.0 / 5e12 +
+                     (double)rest * (double)(N * K) * 2.0 / 0.9e15;     // the caller's library product of the rows left over
+    if (t < best) best = t, s = c;
+  }
+  if (env_s > 0) s = env_s;
   while (s > 1 && M / (128 * s) < 1) --s;
   const int64_t per = M / (128 * s) * 128;
   if (per < 128) return 0;

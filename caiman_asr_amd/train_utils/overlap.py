@@ -62,10 +62,11 @@ WGRAD_SPLIT = 16   # row chunks of the weight-gradient GEMM when the reduction d
 
 def _weight_gradient(dy2, x2):
     """dW = dyᵀ · x for [rows, N] x [rows, K] with a very long `rows` (the joint projection: 300 000 lattice cells):
-    the library's transposed-A kernel tiles only the [N, K] output (8704 x 768 = 102 macro-tiles for 256 CUs) and
-    runs at 0.85 PF/s; cut into 16 row chunks as ONE batched GEMM with fp32 outputs and summed, the same product
-    takes 3.98 instead of 4.76 ms (tools/dbg/dw_split2.py) and the partial sums are fp32 instead of one bf16 rounding
-    of the full sum.  Deterministic: the chunks are added in a fixed order."""
+    the hand-written transposed-read kernel (csrc/joint_wgrad.hip, `_joint_wgrad`) where its geometry fits (N, K
+    multiples of 256), else the library: its transposed-A kernel tiles only the [N, K] output (8704 x 768 = 102 macro-tiles
+    for 256 CUs) and runs at 0.85 PF/s; cut into 16 row chunks as ONE batched GEMM with fp32 outputs and summed, the same
+    product takes 3.98 instead of 4.76 ms and the partial sums are fp32 instead of one bf16 rounding of the full sum.
+    Both are deterministic: slices / chunks are added in a fixed order."""
     rows = dy2.shape[0]
     S = WGRAD_SPLIT
     if not dy2.is_cuda or dy2.dtype not in (torch.float16, torch.bfloat16) or rows < 4096 * S:
@@ -113,8 +114,9 @@ def _joint_gemm(a2, w, bias, want_lse):
     return c, lse
 
 
-# The projection's weight gradient on the hand-written transposed-read GEMM (csrc/joint_wgrad.hip).  CAIMAN_JOINT_WGRAD=1 | 0.
-JOINT_WGRAD = __import__("os").environ.get("CAIMAN_JOINT_WGRAD", "0") != "0"
+# The projection's weight gradient on the hand-written transposed-read GEMM (csrc/joint_wgrad.hip): 3.3-3.4 ms against the
+# library's 3.9-4.0 at 304 000 x 8704 x 768 (tools/joint_gemm_bench.py).  CAIMAN_JOINT_WGRAD=0 restores the batched library call.
+JOINT_WGRAD = __import__("os").environ.get("CAIMAN_JOINT_WGRAD", "1") != "0"
 
 
 def _joint_wgrad(dy2, x2):

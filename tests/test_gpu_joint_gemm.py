@@ -193,3 +193,31 @@ def test_joint_fc_wgrad_plan_rejects_what_the_kernel_cannot_take():
     assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 700, _lib.dtype_tag(torch.bfloat16), ctypes.byref(per)) == 0
     assert lib.caiman_joint_fc_wgrad_plan(100, 512, 512, _lib.dtype_tag(torch.bfloat16), ctypes.byref(per)) == 0
     assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 768, _lib.dtype_tag(torch.float32), ctypes.byref(per)) == 0
+
+
+def test_projection_autograd_takes_the_handwritten_weight_gradient_and_agrees_with_the_library(monkeypatch):
+    """train_utils/overlap.py's projection (the joint_fc of the model) at a row count past the library threshold: the weight
+    gradient comes from caiman_joint_fc_wgrad by default, and equals the batched library product to fp32 summation order."""
+    from caiman_asr_amd.train_utils import overlap
+
+    rows, N, K = 70000, 512, 256
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(rows, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) / 16).requires_grad_()
+    b = torch.zeros(N, device=DEV, requires_grad=True)
+    dy = torch.randn(rows, N, device=DEV, generator=g).to(torch.bfloat16)
+    calls, grads = [], []
+    real = overlap._joint_wgrad
+    monkeypatch.setattr(overlap, "_joint_wgrad", lambda a, c: (calls.append(1), real(a, c))[1])
+    assert overlap.JOINT_WGRAD, "the hand-written weight gradient is the default"
+    for on in (True, False):
+        monkeypatch.setattr(overlap, "JOINT_WGRAD", on)
+        w.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = overlap.linear_transposed_backward(x, w, b)
+        out.backward(dy)
+        grads.append(w.grad.clone())
+    assert len(calls) == 1
+    assert grads[0].dtype == torch.float32
+    err = (grads[0] - grads[1]).abs().max().item()
+    assert err <= 1e-5 * grads[1].abs().max().item(), err
