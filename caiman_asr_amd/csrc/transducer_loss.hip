@@ -456,18 +456,18 @@ __global__ __launch_bounds__(256) void loss_row_desc_kernel(const acc_t<T>* __re
   desc[row] = d;
 }
 
-template <typename T, int VEC, int KACC>
-__global__ __launch_bounds__(256) void loss_bwd_colsum_kernel(const T* __restrict__ x,
+template <typename T, int VEC, int KACC, int NW>
+__global__ __launch_bounds__(64 * NW) void loss_bwd_colsum_kernel(const T* __restrict__ x,
                                                               const RowDesc<acc_t<T>>* __restrict__ desc, int64_t V,
                                                               int64_t blank, int64_t total_rows, T* __restrict__ x_grad,
                                                               int rows_per_block, float* __restrict__ colsum_partial) {
   using A = acc_t<T>;
   using Vt = vecT<T, VEC>;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave, nwave = blockDim.x / kWave;
+  const int wave = threadIdx.x / kWave, nwave = NW;
   // 32-bit column arithmetic throughout (V < 2^31): 64-bit per-element invariants cost dozens of VGPRs
   const int nchunk = (int)(V / VEC);                   // the launch guarantees V % VEC == 0
-  const int quarter = (nchunk + nwave - 1) / nwave;    // and KACC * 64 >= quarter
+  const int quarter = (nchunk + nwave - 1) / nwave;    // and KACC * 64 >= quarter (each wave's share of the chunks)
   const int cbeg = wave * quarter;
   const int cend = cbeg + quarter < nchunk ? cbeg + quarter : nchunk;
   const int blank_col = (int)blank;
@@ -651,9 +651,14 @@ int loss_backward_impl(const void* x, const void* denom, const void* loss_grad, 
     auto gs = static_cast<scalar_t*>(x_grad);
     using AA = const A*;
     if (colsum_partial) {
-      // a lane keeps the sums of its column chunks in registers: chunks per lane = ceil(ceil(V / VEC / 4 waves) / 64 lanes)
+      // a lane keeps the sums of its column chunks in registers: chunks per lane = ceil(ceil(V / VEC / waves) / 64 lanes).
+      // Four waves per workgroup up to 5 chunks per lane (V <= 10 240 at 2 bytes); eight waves past that, which keeps
+      // 17 408 columns (large-196M) at 5 chunks per lane and doubles the widest row the fused sums take.  At 17 408 the
+      // two forms measure the same (4.9 ms for 21 GB of logits + gradient, 4.6 TB/s, as the four-wave kernel at 8704).
       CAIMAN_CHECK(aligned, "transducer_loss_backward_colsum: x, x_grad and the rows must be 16-byte aligned");
-      const int64_t per_lane = ((dict_size / VEC + 3) / 4 + kWave - 1) / kWave;
+      const int64_t per_lane4 = ((dict_size / VEC + 3) / 4 + kWave - 1) / kWave;
+      const bool wide = per_lane4 > 5;
+      const int64_t per_lane = wide ? ((dict_size / VEC + 7) / 8 + kWave - 1) / kWave : per_lane4;
       CAIMAN_CHECK(per_lane <= 16, "transducer_loss_backward_colsum: dict_size %lld too large for the fused column sums",
                    (long long)dict_size);
       // descriptors behind the partial sums: [nblk, V] floats (rounded up to a multiple of 8), then total_rows * 32 bytes
@@ -662,14 +667,17 @@ int loss_backward_impl(const void* x, const void* denom, const void* loss_grad, 
       CAIMAN_CHECK(reinterpret_cast<uintptr_t>(desc) % 32 == 0, "transducer_loss_backward_colsum: workspace must be 32-byte aligned");
       hipLaunchKernelGGL((loss_row_desc_kernel<scalar_t>), dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, s,
                          (AA)denom, (AA)loss_grad, (AA)alpha, (AA)beta, p, total_rows, desc);
-      auto go = [&](auto k_tag) {
-        constexpr int K_ = decltype(k_tag)::value;
-        hipLaunchKernelGGL((loss_bwd_colsum_kernel<scalar_t, VEC, K_>), grid, dim3(256), 0, s, xs, desc, dict_size, blank_idx,
-                           total_rows, gs, (int)rows_per_block, colsum_partial);
+      auto go = [&](auto k_tag, auto w_tag) {
+        constexpr int K_ = decltype(k_tag)::value, W_ = decltype(w_tag)::value;
+        hipLaunchKernelGGL((loss_bwd_colsum_kernel<scalar_t, VEC, K_, W_>), grid, dim3(64 * W_), 0, s, xs, desc, dict_size,
+                           blank_idx, total_rows, gs, (int)rows_per_block, colsum_partial);
       };
-      if (per_lane <= 5) go(std::integral_constant<int, 5>{});
-      else if (per_lane <= 9) go(std::integral_constant<int, 9>{});
-      else go(std::integral_constant<int, 16>{});
+      using w4 = std::integral_constant<int, 4>;
+      using w8 = std::integral_constant<int, 8>;
+      if (!wide) go(std::integral_constant<int, 5>{}, w4{});
+      else if (per_lane <= 5) go(std::integral_constant<int, 5>{}, w8{});
+      else if (per_lane <= 9) go(std::integral_constant<int, 9>{}, w8{});
+      else go(std::integral_constant<int, 16>{}, w8{});
     } else if (aligned) {
       hipLaunchKernelGGL((loss_bwd_kernel<scalar_t, VEC>), grid, dim3(256), 0, s, xs, (AA)denom, (AA)loss_grad, (AA)alpha,
                          (AA)beta, p, total_rows, gs);

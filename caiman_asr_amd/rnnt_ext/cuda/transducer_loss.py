@@ -65,11 +65,12 @@ COLSUM_ROWS_PER_BLOCK = 64
 
 
 def colsum_supported(x) -> bool:
-    """The fused column sums need 16-byte aligned rows and at most 16 column chunks per lane (V <= 32768 for 16-bit
-    logits); anything else takes the plain backward and a reduction."""
+    """The fused column sums need 16-byte aligned rows and at most 16 column chunks per lane of an eight-wave workgroup
+    (V <= 65536 for 16-bit logits; four waves up to 5 chunks per lane, csrc/transducer_loss.hip); anything else takes the
+    plain backward and a reduction."""
     V, es = x.shape[-1], x.element_size()
     return (x.is_cuda and V > 0 and (V * es) % 16 == 0 and x.data_ptr() % 16 == 0
-            and ((V * es // 16 + 3) // 4 + 63) // 64 <= 16)
+            and ((V * es // 16 + 7) // 8 + 63) // 64 <= 16)
 
 
 def backward_colsum(x, denom, loss_grad, alpha, beta, aud_len, txt_len, label, batch_offset, dp_lam,

@@ -185,11 +185,13 @@ def test_nan_denominator_propagates_and_errors():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("packed", [True, False])
-@pytest.mark.parametrize("V,B,T,U", [(29, 3, 9, 5), (8704, 2, 41, 6), (17408, 2, 19, 4)])
+@pytest.mark.parametrize("V,B,T,U", [(29, 3, 9, 5), (8704, 2, 41, 6), (12288, 2, 23, 3), (17408, 2, 19, 4), (40960, 1, 9, 3)])
 def test_backward_with_fused_column_sums(dtype, packed, V, B, T, U):
     """caiman_transducer_loss_backward_colsum: the same gradient as the plain backward, bit for bit, plus its column
     sums (the bias gradient of the projection that produced the logits; the reference takes `grad_output.sum(0)` in a
-    separate pass).  Row counts that are no multiple of the 64 rows a workgroup takes; V = 17 408 needs > 64 KB of LDS."""
+    separate pass).  Row counts that are no multiple of the 64 rows a workgroup takes.  V <= 10 240 (16-bit): four waves per
+    workgroup; 12 288 and 17 408: eight waves at 3 and 5 chunks per lane; 40 960: eight waves, 10 chunks (the 16-chunk build);
+    fp32 doubles the chunk counts (17 408: 9 per lane of eight waves)."""
     import caiman_asr_amd.rnnt_ext.cuda.logsumexp as lse
     import caiman_asr_amd.rnnt_ext.cuda.transducer_loss as tl
     from tests.helpers import mock_lattice
