@@ -24,6 +24,7 @@
 // HBM once.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -67,7 +68,8 @@ constexpr int WROW = 256;                                  // elements per LDS r
 template <typename T>
 __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Hm,
                                                                  float* __restrict__ slabs, int N, int K, int rows_per_slice,
-                                                                 int tiles_k, int n_tiles) {
+                                                                 int tiles_k, int n_tiles, int slices, int64_t stride_y,
+                                                                 int64_t stride_h) {
   using frag = typename wfrag<T>::type;
   __shared__ __attribute__((aligned(1024))) T sA0[WBM * WROW], sA1[WBM * WROW], sA2[WBM * WROW], sA3[WBM * WROW];   // dY rows
   __shared__ __attribute__((aligned(1024))) T sB0[WBM * WROW], sB1[WBM * WROW], sB2[WBM * WROW], sB3[WBM * WROW];   // h rows
@@ -79,10 +81,13 @@ __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __res
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // t -> (slice of M, n-tile, k-tile): k-tile fastest, so the workgroups that share a dY panel are neighbours
-  const int slice = t / n_tiles, tt = t - slice * n_tiles;
+  // t -> (problem, slice of M, n-tile, k-tile): k-tile fastest, so the workgroups that share a dY panel are neighbours
+  const int pslice = t / n_tiles, tt = t - pslice * n_tiles;      // pslice = problem * slices + slice: the slab this tile writes
+  const int prob = pslice / slices, slice = pslice - prob * slices;
   const int n0 = (tt / tiles_k) * WBN, k0 = (tt % tiles_k) * WBK;
   const int64_t m_begin = (int64_t)slice * rows_per_slice;
+  dY += (int64_t)prob * stride_y;
+  Hm += (int64_t)prob * stride_h;
 
   // DMA sources: a stage = 32 rows x 512 B per operand = 16 instructions of 2 rows; wave w brings instructions w and w + 8.
   // Lane l writes the 16-byte piece at (row l >> 5, position l & 31) and fetches the piece that belongs there: granule
@@ -167,30 +172,47 @@ __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __res
     __builtin_amdgcn_sched_barrier(0);
     compute(cA, cB);
   };
-  const int nk = rows_per_slice / WBM;    // a multiple of four, at least four
+  // drain step: `w` = the wait that leaves the later stages in flight (vmcnt 8, 4, 0 for the last three steps)
+  auto drain = [&](const T* cA, const T* cB, auto w) {
+    __builtin_amdgcn_s_waitcnt(decltype(w)::value);
+    __builtin_amdgcn_s_barrier();
+    compute(cA, cB);
+  };
+  using w8 = std::integral_constant<int, 0x0078>;
+  using w4 = std::integral_constant<int, 0x0074>;
+  using w0 = std::integral_constant<int, 0x0070>;
+  const int nk = rows_per_slice / WBM;    // at least three
   issue(sA0, sB0, 0);
   issue(sA1, sB1, 1);
   issue(sA2, sB2, 2);
   int s = 0;
-  for (; s + 4 <= nk - 3; s += 4) {
+  for (; s + 7 <= nk; s += 4) {           // four steady steps need stages s + 3 .. s + 6
     steady(sA0, sB0, sA3, sB3, s);
     steady(sA1, sB1, sA0, sB0, s + 1);
     steady(sA2, sB2, sA1, sB1, s + 2);
     steady(sA3, sB3, sA2, sB2, s + 3);
   }
-  steady(sA0, sB0, sA3, sB3, s);
-  __builtin_amdgcn_s_waitcnt(0x0078);
-  __builtin_amdgcn_s_barrier();
-  compute(sA1, sB1);
-  __builtin_amdgcn_s_waitcnt(0x0074);
-  __builtin_amdgcn_s_barrier();
-  compute(sA2, sB2);
-  __builtin_amdgcn_s_waitcnt(0x0070);
-  __builtin_amdgcn_s_barrier();
-  compute(sA3, sB3);
+  // 3 .. 6 steps are left, the current one in buffer 0: (left - 3) steady steps, then the three that only drain
+  switch (nk - s) {
+    case 3:
+      drain(sA0, sB0, w8{}); drain(sA1, sB1, w4{}); drain(sA2, sB2, w0{});
+      break;
+    case 4:
+      steady(sA0, sB0, sA3, sB3, s);
+      drain(sA1, sB1, w8{}); drain(sA2, sB2, w4{}); drain(sA3, sB3, w0{});
+      break;
+    case 5:
+      steady(sA0, sB0, sA3, sB3, s); steady(sA1, sB1, sA0, sB0, s + 1);
+      drain(sA2, sB2, w8{}); drain(sA3, sB3, w4{}); drain(sA0, sB0, w0{});
+      break;
+    default:
+      steady(sA0, sB0, sA3, sB3, s); steady(sA1, sB1, sA0, sB0, s + 1); steady(sA2, sB2, sA1, sB1, s + 2);
+      drain(sA3, sB3, w8{}); drain(sA0, sB0, w4{}); drain(sA1, sB1, w0{});
+      break;
+  }
 
   // epilogue: D[i][j] of a block sits in lane (j = lane & 15, i = 4 (lane >> 4) + reg): rows = n (A operand), columns = k
-  float* out = slabs + ((int64_t)slice * N + n0 + wr * 128) * K + k0 + wc * 64;
+  float* out = slabs + ((int64_t)pslice * N + n0 + wr * 128) * K + k0 + wc * 64;
 #pragma unroll
   for (int a = 0; a < WTN; ++a)
 #pragma unroll
@@ -202,55 +224,86 @@ __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __res
 }  // namespace
 }  // namespace caiman
 
-// Slices of M the kernel wants for a [M, N] x [M, K] product on this chip (>= 1), and the rows it then covers:
-// rows_covered = slices * rows_per_slice with rows_per_slice a multiple of 128; 0 slices: shape not supported.
-extern "C" int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice) {
-  if (!(dtype == CAIMAN_BF16 || dtype == CAIMAN_F16) || N < 256 || N % 256 || K < 256 || K % 256 || M < 512) return 0;
+namespace caiman {
+namespace {
+// One workgroup per CU (128 KB of LDS), so the grid runs in rounds of 256 workgroups and a slice count is as good as its
+// last round is full: time(s) = rounds(s) x (steps per slice x 0.86 us + 17 us) + s slabs per product written and read back at
+// ~5 TB/s + the caller's library product of the rows left over.  0.86 us = the measured step of 32 rows; 17 us = what a
+// workgroup spends outside its loop (three stages of DMA latency in front, 256 KB of fp32 partial tile behind: short slices
+// pay it per round -- five LSTM layers at 8 900 rows measured 669 us where the loop alone predicts 350).
+// 8704 x 768 (joint): 102 tiles -> 5 slices (510 workgroups, 2 rounds); 17408 x 1024: 272 tiles -> 16 slices (17 rounds; one slice
+// would leave the second round 6 % full); six LSTM layers of 4096 x 1024 at 8 900 rows: 384 tiles -> 2 slices (3 rounds).
+int wgrad_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* rows_per_slice, double* seconds) {
+  if (!(dtype == CAIMAN_BF16 || dtype == CAIMAN_F16) || N < 256 || N % 256 || K < 256 || K % 256 || M < 128 || batch < 1)
+    return 0;
   if (N * 2 * 32 >= ((int64_t)1 << 31) || M * N >= ((int64_t)1 << 46)) return 0;
-  const int64_t tiles = (N / 256) * (K / 256);
+  const int64_t tiles = (N / 256) * (K / 256) * batch;
   static const int env_s = std::getenv("CAIMAN_WGRAD_SLICES") ? std::atoi(std::getenv("CAIMAN_WGRAD_SLICES")) : 0;
-  // One workgroup per CU (128 KB of LDS), so the grid runs in rounds of 256 workgroups and a slice count is as good as its
-  // last round is full: time(s) = rounds(s) x steps per slice x 0.86 us (measured step of 32 rows) + s slabs written
-  // and read back at ~5 TB/s.  8704 x 768: 102 tiles -> 5 slices (510 workgroups, 2 rounds); 17408 x 1024: 272 tiles ->
-  // 16 slices (4352 workgroups, 17 rounds) -- one slice would leave the second round 6 % full.
   constexpr int64_t kCus = 256;
+  auto cost = [&](int64_t c) {
+    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (32 * c), rest = M - c * steps * 32;
+    return (double)rounds * ((double)steps * 0.86e-6 + 17e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
+           (double)(rest * batch) * (double)(N * K) * 2.0 / 0.9e15;
+  };
   int64_t s = 1;
   double best = 1e30;
-  for (int64_t c = 1; c <= 32 && M / (128 * c) >= 4; ++c) {
-    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (128 * c) * 4, rest = M - c * steps * 32;
-    const double t = (double)rounds * (double)steps * 0.86e-6 + (double)c * (double)(N * K) * 8.0 / 5e12 +
-                     (double)rest * (double)(N * K) * 2.0 / 0.9e15;     // the caller's library product of the rows left over
-    if (t < best) best = t, s = c;
-  }
+  for (int64_t c = 1; c <= 32 && M / (32 * c) >= 4; ++c)
+    if (cost(c) < best) best = cost(c), s = c;
   if (env_s > 0) s = env_s;
-  while (s > 1 && M / (128 * s) < 1) --s;
-  const int64_t per = M / (128 * s) * 128;
+  while (s > 1 && M / (32 * s) < 4) --s;
+  const int64_t per = M / (32 * s) * 32;
   if (per < 128) return 0;
   if (rows_per_slice) *rows_per_slice = per;
+  if (seconds) *seconds = cost(s);
   return (int)s;
 }
+}  // namespace
+}  // namespace caiman
 
-// slabs [slices][N][K] fp32 (written, not accumulated): slab s = sum over rows [s * rows_per_slice, +rows_per_slice) of
-// dY[m][n] * h[m][k].  Rows from slices * rows_per_slice on are the caller's.
-extern "C" int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
-                                     int64_t rows_per_slice, int dtype, caiman_stream_t stream) {
+// Slices of M the kernel wants for `batch` products [M, N]^T x [M, K] of one shape on this chip (>= 1), and the rows they
+// cover: rows_covered = slices * rows_per_slice with rows_per_slice a multiple of 32 (>= 128); 0 slices: shape not supported.
+extern "C" int caiman_wgrad_tn_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* rows_per_slice) {
+  return caiman::wgrad_plan(M, N, K, batch, dtype, rows_per_slice, nullptr);
+}
+// What the plan's cost model expects the call to take, in microseconds (negative: shape not supported) -- for callers that
+// have a library product to fall back on and want the kernel only where it is expected to win.
+extern "C" double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, int batch, int dtype) {
+  double sec = 0.0;
+  return caiman::wgrad_plan(M, N, K, batch, dtype, nullptr, &sec) > 0 ? sec * 1e6 : -1.0;
+}
+
+// `batch` products of one shape: operand p at dY + p * stride_y / H + p * stride_h (elements; rows of N / K elements,
+// contiguous).  slabs [batch][slices][N][K] fp32 (written, not accumulated): slab (p, s) = sum over rows
+// [s * rows_per_slice, +rows_per_slice) of dY_p[m][n] * H_p[m][k].  Rows from slices * rows_per_slice on are the caller's.
+extern "C" int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch,
+                               int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype,
+                               caiman_stream_t stream) {
   using namespace caiman;
-  int64_t per = 0;
-  CAIMAN_CHECK(caiman_joint_fc_wgrad_plan(M, N, K, dtype, &per) > 0, "joint_fc_wgrad: bf16 / f16, N, K %% 256 == 0, M >= 512");
-  CAIMAN_CHECK(slices >= 1 && rows_per_slice >= 128 && rows_per_slice % 128 == 0 && (int64_t)slices * rows_per_slice <= M,
-               "joint_fc_wgrad: slices x rows_per_slice must be multiples of 128 rows inside M");
-  CAIMAN_CHECK(dY && H && slabs, "joint_fc_wgrad: null pointer");
+  CAIMAN_CHECK(caiman_wgrad_tn_plan(M, N, K, batch, dtype, nullptr) > 0, "wgrad_tn: bf16 / f16, N, K %% 256 == 0, M >= 128");
+  CAIMAN_CHECK(slices >= 1 && rows_per_slice >= 96 && rows_per_slice % 32 == 0 && (int64_t)slices * rows_per_slice <= M,
+               "wgrad_tn: slices x rows_per_slice must be multiples of 32 rows (>= 96) inside M");
+  CAIMAN_CHECK(dY && H && slabs, "wgrad_tn: null pointer");
   auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-  CAIMAN_CHECK(al(dY, 16) && al(H, 16) && al(slabs, 16), "joint_fc_wgrad: 16-byte aligned operands");
+  CAIMAN_CHECK(al(dY, 16) && al(H, 16) && al(slabs, 16) && stride_y % 8 == 0 && stride_h % 8 == 0 && stride_y >= 0 && stride_h >= 0,
+               "wgrad_tn: 16-byte aligned operands and batch strides");
   const int tiles_k = (int)(K / WBK), n_tiles = (int)(N / WBN) * tiles_k;
-  const int64_t grid = (int64_t)n_tiles * slices;
-  CAIMAN_CHECK(grid < ((int64_t)1 << 31), "joint_fc_wgrad: too many tiles");
+  const int64_t grid = (int64_t)n_tiles * slices * batch;
+  CAIMAN_CHECK(grid < ((int64_t)1 << 31), "wgrad_tn: too many tiles");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == CAIMAN_BF16)
     hipLaunchKernelGGL((joint_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const bf16_t*)dY, (const bf16_t*)H,
-                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles);
+                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h);
   else
     hipLaunchKernelGGL((joint_wgrad_kernel<f16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const f16_t*)dY, (const f16_t*)H,
-                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles);
-  return check_launch("joint projection weight gradient");
+                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h);
+  return check_launch("transposed-read weight gradient");
+}
+
+// The joint projection's instance (one product): include/caiman_rnnt.h.
+extern "C" int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice) {
+  return M < 512 ? 0 : caiman_wgrad_tn_plan(M, N, K, 1, dtype, rows_per_slice);
+}
+extern "C" int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
+                                     int64_t rows_per_slice, int dtype, caiman_stream_t stream) {
+  return caiman_wgrad_tn(dY, 0, H, 0, slabs, 1, M, N, K, slices, rows_per_slice, dtype, stream);
 }

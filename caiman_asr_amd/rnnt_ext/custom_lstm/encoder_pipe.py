@@ -37,6 +37,9 @@ PROJ_TILE = int(__import__("os").environ.get("CAIMAN_PROJ_TILE", "0"))
 # backward ticks (K = 4H, about one 128 x 128 tile per CU): the variant whose workgroup splits K between two wave groups
 PROJ_TILE_BWD = int(__import__("os").environ.get("CAIMAN_PROJ_TILE_BWD", "8"))
 IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # one launch for all operand images of the weights
+# the layers' weight gradients dG^T . x / dG^T . h_prev on the transposed-read kernel (csrc/joint_wgrad.hip, fp32 results)
+# instead of the library's transposed-A GEMMs; shapes outside its geometry (K = 240 of layer 0) keep the library
+WGRAD_TN = int(__import__("os").environ.get("CAIMAN_LSTM_WGRAD_TN", "1")) != 0
 
 
 def _proj_ok(widths, dt):
@@ -536,12 +539,23 @@ class EncoderPipeFunction(torch.autograd.Function):
 
         # post layers have identical shapes: their recurrent-weight gradients (all Lb), their input-weight gradients
         # (layers 1..Lb-1) and all bias gradients are three batched calls instead of 3 * Lb
+        def tn(dg3, x3):
+            """dg3 [P, rows, 4H]^T . x3 [P, rows, K] -> [P, 4H, K]: the hand-written kernel where it applies, else the library"""
+            out = overlap.wgrad_tn(dg3, x3, only_if_faster=True) if WGRAD_TN else None
+            return out if out is not None else torch.bmm(dg3.transpose(1, 2), x3)
+
+        def rows3(t, first, count, skip, T):
+            """layers [first, first + count) of t [layers, T (+ 1), B, H], steps [skip, skip + T) -> [count, T * B, H] without
+            a copy (rows contiguous, layers a constant stride apart)"""
+            v = t[first:first + count, skip:skip + T]
+            return torch.as_strided(v, (count, T * B, v.shape[-1]), (t.stride(0), v.shape[-1], 1), v.storage_offset())
+
         post_R = post_W = post_b = None
         if BMM and Lb > 1:
             dgb = dGb.view(Lb, T2 * B, 4 * H)
-            post_R = torch.bmm(dgb.transpose(1, 2), Yb[:, :T2].reshape(Lb, T2 * B, H))
-            xin = (YMb[:Lb - 1] if pl[La] > 0.0 else Yb[:Lb - 1, 1:]).reshape(Lb - 1, T2 * B, H)
-            post_W = torch.bmm(dgb[1:].transpose(1, 2), xin)
+            post_R = tn(dgb, rows3(Yb, 0, Lb, 0, T2))
+            xin = rows3(YMb, 0, Lb - 1, 0, T2) if pl[La] > 0.0 else rows3(Yb, 0, Lb - 1, 1, T2)
+            post_W = tn(dgb[1:], xin)
             post_b = None if fused_db else dgb.sum(1)
         per_layer = [None] * L
         for l in (reversed(range(L)) if direct else range(L)):
@@ -550,12 +564,12 @@ class EncoderPipeFunction(torch.autograd.Function):
             m = l - La
             if post_R is not None and 0 <= m < Lb:
                 dB = dbias[l, :4 * hl] if fused_db else post_b[m]
-                gW = post_W[m - 1] if m >= 1 else torch.matmul(dg.t(), layer_input(l))
+                gW = post_W[m - 1] if m >= 1 else tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0]
                 g4 = [gW, post_R[m], dB, dB]
             else:
                 yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
                 dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)
-                g4 = [torch.matmul(dg.t(), layer_input(l)), torch.matmul(dg.t(), yprev), dB, dB]
+                g4 = [tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0], tn(dg.unsqueeze(0), yprev.unsqueeze(0))[0], dB, dB]
             if direct:
                 ps = ctx.params[4 * l:4 * l + 4]
                 if (IMAGES and all(p_.requires_grad and p_.dtype == torch.float32 and p_.is_contiguous() for p_ in ps)

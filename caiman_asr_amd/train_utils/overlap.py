@@ -119,27 +119,52 @@ def _joint_gemm(a2, w, bias, want_lse):
 JOINT_WGRAD = __import__("os").environ.get("CAIMAN_JOINT_WGRAD", "1") != "0"
 
 
-def _joint_wgrad(dy2, x2):
-    """dy2 [M, N]^T . x2 [M, K] -> [N, K] fp32 through caiman_joint_fc_wgrad (slices of M into fp32 slabs, added in order,
-    plus the library product of the few rows the slices do not cover), or None when the shape is outside the kernel."""
+LIBRARY_TN_FLOPS = 0.8e15   # what the library's transposed-A GEMM reaches at the LSTM layers' shapes (tools/wgrad_tn_bench.py: 0.62-1.03)
+
+
+def wgrad_tn(dy3, x3, only_if_faster=False):
+    """dy3 [P, M, N]^T . x3 [P, M, K] per p -> [P, N, K] fp32 through caiman_wgrad_tn (csrc/joint_wgrad.hip: slices of M into
+    fp32 slabs, added in order, plus the library product of the few rows the slices do not cover), or None when the shapes or
+    strides are outside the kernel (rows must be contiguous, the P operands a constant stride apart) -- or, with
+    `only_if_faster`, when the kernel's own cost model expects the library to be quicker (short reductions whose tile
+    count fills the last round of 256 workgroups badly)."""
     import ctypes
 
     from caiman_asr_amd import _lib
 
-    M, N = dy2.shape
-    K = x2.shape[1]
-    lib, tag = _lib.lib(), _lib.dtype_tag(dy2.dtype)
+    P, M, N = dy3.shape
+    K = x3.shape[2]
+    if (not dy3.is_cuda or dy3.dtype not in (torch.float16, torch.bfloat16) or x3.dtype != dy3.dtype or x3.shape[:2] != (P, M)
+            or dy3.stride(2) != 1 or dy3.stride(1) != N or x3.stride(2) != 1 or x3.stride(1) != K):
+        return None
+    sy, sx = (dy3.stride(0), x3.stride(0)) if P > 1 else (0, 0)
+    if sy % 8 or sx % 8 or sy < 0 or sx < 0 or dy3.data_ptr() % 16 or x3.data_ptr() % 16:
+        return None
+    lib, tag = _lib.lib(), _lib.dtype_tag(dy3.dtype)
+    if only_if_faster:
+        est = lib.caiman_wgrad_tn_estimate_us(M, N, K, P, tag)
+        if est < 0 or est * 1e-6 > 2.0 * P * M * N * K / LIBRARY_TN_FLOPS:
+            return None
     per = ctypes.c_int64(0)
-    slices = lib.caiman_joint_fc_wgrad_plan(M, N, K, tag, ctypes.byref(per))
+    slices = lib.caiman_wgrad_tn_plan(M, N, K, P, tag, ctypes.byref(per))
     if slices <= 0:
         return None
-    slabs = torch.empty((slices, N, K), dtype=torch.float32, device=dy2.device)
-    _lib.check(lib.caiman_joint_fc_wgrad(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(slabs), M, N, K, slices, per.value, tag, _lib.stream()))
-    dw = slabs.sum(0)
+    slabs = torch.empty((P, slices, N, K), dtype=torch.float32, device=dy3.device)
+    _lib.check(lib.caiman_wgrad_tn(_lib.ptr(dy3), sy, _lib.ptr(x3), sx, _lib.ptr(slabs), P, M, N, K, slices, per.value, tag,
+                                   _lib.stream()))
+    dw = slabs.sum(1) if slices > 1 else slabs[:, 0]
     done = slices * per.value
     if done < M:
-        dw += torch.mm(dy2[done:].t(), x2[done:], out_dtype=torch.float32)
+        dw += torch.bmm(dy3[:, done:].transpose(1, 2), x3[:, done:], out_dtype=torch.float32)
     return dw
+
+
+def _joint_wgrad(dy2, x2):
+    """The joint projection's instance: dy2 [M, N]^T . x2 [M, K] -> [N, K] fp32, or None (shape outside the kernel)."""
+    if dy2.shape[0] < 512:
+        return None
+    out = wgrad_tn(dy2.unsqueeze(0), x2.unsqueeze(0))
+    return None if out is None else out[0]
 
 
 class _LinearTransposedBackward(torch.autograd.Function):

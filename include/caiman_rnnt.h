@@ -335,12 +335,21 @@ int caiman_joint_fc_forward(const void* A, const void* W, const void* bias, void
                             int64_t M, int64_t N, int64_t K, int dtype, caiman_stream_t stream);
 /* Weight gradient of the same projection (csrc/joint_wgrad.hip) — replaces autograd's dW = dY^T . h of torch.nn.Linear
  * (training/caiman_asr_train/rnnt/model.py:409-439): dY [M, N], H [M, K] in `dtype`, the reduction over M split into
- * `slices` consecutive row ranges of `rows_per_slice` rows (caiman_joint_fc_wgrad_plan chooses both; 0 = shape not
- * supported: N, K % 256 == 0, bf16 / f16); slabs [slices][N][K] fp32 receives one partial product per slice (written, not
- * accumulated).  The caller adds the slabs in order, plus the product of the rows past slices * rows_per_slice. */
+ * `slices` consecutive row ranges of `rows_per_slice` rows (a multiple of 32; caiman_joint_fc_wgrad_plan chooses both; 0 =
+ * shape not supported: N, K % 256 == 0, bf16 / f16); slabs [slices][N][K] fp32 receives one partial product per slice
+ * (written, not accumulated).  The caller adds the slabs in order, plus the product of the rows past slices * rows_per_slice. */
 int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice);
 int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
                           int64_t rows_per_slice, int dtype, caiman_stream_t stream);
+/* The same kernel for `batch` products of one shape — the LSTM layers' weight gradients dW = dG^T . x, dR = dG^T . h_prev,
+ * which the reference takes as `torch.matmul(dG.t(), x)` per layer (training/lib/src/rnnt_ext/custom_lstm/lstm.py:128-142):
+ * operand p at dY + p * stride_y / H + p * stride_h (elements), slabs [batch][slices][N][K]. */
+int caiman_wgrad_tn_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* rows_per_slice);
+/* microseconds the plan's cost model expects (round quantisation over 256 CUs, per-workgroup fixed cost, slabs); < 0: shape
+ * not supported.  For callers that keep the kernel to the calls where it is expected to beat their library product. */
+double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, int batch, int dtype);
+int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch, int64_t M,
+                    int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not

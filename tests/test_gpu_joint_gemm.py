@@ -221,3 +221,39 @@ def test_projection_autograd_takes_the_handwritten_weight_gradient_and_agrees_wi
     assert grads[0].dtype == torch.float32
     err = (grads[0] - grads[1]).abs().max().item()
     assert err <= 1e-5 * grads[1].abs().max().item(), err
+
+
+@pytest.mark.parametrize("P,M,N,K,pad", [
+    (1, 131, 256, 256, 0),       # four stages and three rows for the library remainder
+    (3, 1000, 512, 256, 64),     # operands a constant stride apart (64 spare rows between them), 1000 = 31 x 32 + 8
+    (6, 8896, 4096, 1024, 32),   # six post-encoder LSTM layers at B = 32: dR = dG^T . h_prev
+    (5, 2300, 1024, 2048, 0),    # K = 2048 (stacked input)
+])
+def test_batched_weight_gradients_match_fp64_products(P, M, N, K, pad):
+    """caiman_wgrad_tn: `P` products of one shape in one launch (the LSTM layers' dW / dR), operands read in place from
+    buffers with spare rows between the layers (the pipeline's [layers, T + 1, B, H] activations)."""
+    from caiman_asr_amd.train_utils.overlap import wgrad_tn
+
+    g = torch.Generator(device=DEV).manual_seed(P * M + N + K)
+    dy_all = torch.randn(P, M + pad, N, device=DEV, generator=g).to(torch.bfloat16)
+    x_all = torch.randn(P, M + pad, K, device=DEV, generator=g).to(torch.bfloat16)
+    dy, x = dy_all[:, pad:], x_all[:, :M]          # views: different offsets, same constant stride
+    x[:, :, 7] = 0.0
+    dw = wgrad_tn(dy, x)
+    assert dw is not None and dw.shape == (P, N, K) and dw.dtype == torch.float32
+    torch.cuda.synchronize()
+    for p in range(P):
+        ref = dy[p].double().t() @ x[p].double()
+        err = (dw[p].double() - ref).abs().max().item()
+        assert err <= 2e-5 * ref.abs().max().item(), (p, err)
+        assert (dw[p][:, 7] == 0).all()
+
+
+def test_wgrad_tn_declines_what_it_cannot_address():
+    from caiman_asr_amd.train_utils.overlap import wgrad_tn
+
+    a = torch.zeros(2, 512, 256, device=DEV, dtype=torch.bfloat16)
+    assert wgrad_tn(a, torch.zeros(2, 512, 240, device=DEV, dtype=torch.bfloat16)) is None      # K = 240 (layer 0)
+    assert wgrad_tn(a.transpose(1, 2), a.transpose(1, 2)) is None                                   # rows not contiguous
+    assert wgrad_tn(a.float(), a.float()) is None                                                   # fp32 operands
+    assert wgrad_tn(a[:, :100], a[:, :100]) is None                                                 # fewer than 128 rows
