@@ -2,7 +2,7 @@
 # final tree: full GPU suite, smoke, default bench line (with decode + cpu baseline), variants, phase timers
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r3n
+O=$R/gpurun_out/${RUN_TAG:-r3n}
 mkdir -p $O
 cd $R
 timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > $O/t_all.log 2>&1; echo "ALL gpu tests rc=$?"; tail -3 $O/t_all.log
@@ -16,7 +16,7 @@ timeout -k 10 300 python3 tools/lstm_resident_bench.py --skip-agreement > $O/pha
 timeout -k 10 300 python3 tools/lstm_resident_bench.py --skip-agreement --hidden 1536 --layers 5 > $O/phase_1536.log 2>&1; echo "phase 1536 rc=$?"
 python3 - <<'PY'
 import glob, json
-for f in sorted(glob.glob("gpurun_out/r3n/*.json")):
+for f in sorted(glob.glob("gpurun_out/" + __import__("os").environ.get("RUN_TAG", "r3n") + "/*.json")):
     try:
         d = json.load(open(f))
         print(f, round(d["ms_per_step"], 2), round(d["value"], 3), d.get("kernel_ms_per_step"), d["lstm_resident"], d.get("feed"), (d.get("decode") or {}).get("tick_latency_ms"), d.get("rehearsal"))
