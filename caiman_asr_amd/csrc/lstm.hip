@@ -1188,12 +1188,24 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
 
   int s = 0, bt = 0;
   bool have = false, aborted = false;     // have: this tile-step's operands were gathered during the previous one
+#ifdef BT_PROF
+  const bool prof = tid == 0 && slot == 0 && j == 0;
+  long long tp[4] = {0, 0, 0, 0}, pt = 0;
+  unsigned n_slow = 0, n_notready = 0, n_ts = 0;
+  if (prof) pt = wall_clock64();
+#define BT_MARK(i) if (prof) { const long long now_ = wall_clock64(); tp[i] += now_ - pt; pt = now_; }
+#else
+#define BT_MARK(i)
+#endif
   auto body = [&](T* c0, T* n0) {
     const T* cg = c0 + NST * 32 * LDW;
     T* g = w.g[slot] + go * s;
     unsigned* cnt = counter(bt);
     const int row0 = bt * 32;
     const int bt_n = bt + 1 < ntiles ? bt + 1 : 0, s_n = bt + 1 < ntiles ? s : s + 1;
+#ifdef BT_PROF
+    if (prof) { ++n_ts; if (!have) ++n_slow; }
+#endif
     if (!have) {   // (first tile-step, or the tile was not complete when the previous tile-step looked) wait, then gather now
       if (s > 0 && tid == 0) {
         if (!res_wait(cnt, (unsigned)nwg * (unsigned)s, fail_dev, fail_host)) flag[0] = 1;
@@ -1218,6 +1230,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
     __builtin_amdgcn_s_barrier();
     const bool ready = flag[1] != 0;
     const bool more = s_n < nsteps;
+#ifdef BT_PROF
+    if (prof && !ready) ++n_notready;
+#endif
+    BT_MARK(0)
     gather(n0, ready ? s_n : s, ready ? bt_n : bt, more ? s_n : s, more ? bt_n : bt);     // flies under the MFMAs below
     f32x4 acc[2][2];
 #pragma unroll
@@ -1257,6 +1273,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
         }
       }
     }
+    BT_MARK(1)
     // cell update, lane-local: acc register q = gate q of (unit kq of the row tile, batch row r of the column tile)
     T* cl = cells + (bt * 256 + tid) * 4;
 #pragma unroll
@@ -1312,9 +1329,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
         }
       }
     }
+    BT_MARK(2)
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): every storing wave drains (and the next tile-step's DMAs have landed)
     __syncthreads();
     if (tid == 0 && s + 1 < nsteps) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    BT_MARK(3)
     have = ready;
     bt = bt_n;
     s = s_n;
@@ -1324,6 +1343,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
     body(bufE, bufO);
     if (i + 1 < total && !aborted) body(bufO, bufE);
   }
+#ifdef BT_PROF
+  if (prof) {
+    for (int i = 0; i < 4; ++i)
+      __hip_atomic_fetch_add(fail_host + kResProfFwd + i, (unsigned)tp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfFwd + 4, n_ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfBwd + 0, n_slow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(fail_host + kResProfBwd + 1, n_notready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#endif
+#undef BT_MARK
 }
 
 // Forward resident kernel with the h row gathered by LDS-DMA (H = 512, 1024, 1536): lstm_fwd_resident pulls the row
