@@ -101,4 +101,37 @@ __device__ __forceinline__ T block_reduce(T v, F op, T* smem) {
   return r;
 }
 
+
+// Dropout without mask tensors: keep(seed, element counter) is a pure function of the seed and the element's position in
+// its tensor, evaluated wherever the mask is needed (forward epilogues, and again in the backward of the layer below).
+// One splitmix64 hash serves FOUR consecutive elements (16 bits each: P(drop) = floor(65536 p) / 65536): a 64-bit hash is
+// three 64-bit multiplies = twelve quarter-rate 32-bit multiplies, ~250 cycles of a wave -- per element that made the
+// joint's forward kernel ALU-bound (0.33 ms for 0.47 GB) and sat in the LSTM forward chain's epilogue.
+__device__ __forceinline__ uint64_t drop_hash(uint64_t seed, uint64_t group) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (group + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(p * 65536.f); }
+__device__ __forceinline__ bool drop_pick(uint64_t z, unsigned sub, unsigned threshold) {   // true: the element is dropped
+  return ((unsigned)(z >> (16u * sub)) & 0xFFFFu) < threshold;
+}
+// one element: 0 (dropped) or inv_keep
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  return drop_pick(drop_hash(seed, idx >> 2), (unsigned)(idx & 3), drop_threshold(p)) ? 0.f : inv_keep;
+}
+// elements idx .. idx + 3: one hash when idx is a multiple of four (every caller's case: rows of H % 4 == 0 elements)
+__device__ __forceinline__ void drop_scale4(uint64_t seed, uint64_t idx, float p, float inv_keep, float (&out)[4]) {
+  if ((idx & 3) == 0) {
+    const uint64_t z = drop_hash(seed, idx >> 2);
+    const unsigned thr = drop_threshold(p);
+#pragma unroll
+    for (unsigned q = 0; q < 4; ++q) out[q] = drop_pick(z, q, thr) ? 0.f : inv_keep;
+  } else {
+#pragma unroll
+    for (unsigned q = 0; q < 4; ++q) out[q] = drop_scale(seed, idx + q, p, inv_keep);
+  }
+}
+
 }  // namespace caiman

@@ -20,14 +20,6 @@ struct alignas(sizeof(T) * VEC) vecj {
   T v[VEC];
 };
 
-// splitmix64-style counter hash -> uniform in [0,1)
-__device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 
 struct JointShape {
   const int32_t* f_len;
@@ -82,25 +74,40 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T* __restrict__ f,
   const T* fr = f + ((int64_t)b * s.T + t) * s.H;
   const T* gr = g + ((int64_t)b * s.U + u) * s.H;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  auto one = [&](float a, float c, int64_t h) -> float {
+  // `ks`: 1 without dropout, else 0 (dropped) or 1 / (1 - p) (common.h drop_scale: one hash per four consecutive elements)
+  auto one = [&](float a, float c, float ks) -> float {
     float v = a + c;
     // NaN-propagating like torch.relu (the reference's CPU joint, model.py:441-447): a non-finite encoder / prediction
     // output must reach the loss as NaN so that the batch is dropped (core.py:20-42), not be clamped to 0 here
     if (relu) v = (v > 0.f || v != v) ? v : 0.f;
-    if (drop_p > 0.f) v = (uniform_from(seed, (uint64_t)(row * s.H + h)) < drop_p) ? 0.f : v * keep_scale;
-    return v;
+    return drop_p > 0.f ? (ks == 0.f ? 0.f : v * ks) : v;
   };
   for (int64_t c = lane; c < nfull; c += kWave) {
     const V a = *reinterpret_cast<const V*>(fr + c * VEC);
     const V d = *reinterpret_cast<const V*>(gr + c * VEC);
     V r;
+    if constexpr (VEC % 4 == 0) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j)
-      r.v[j] = static_cast<T>(one(static_cast<float>(a.v[j]), static_cast<float>(d.v[j]), c * VEC + j));
+      for (int j4 = 0; j4 < VEC; j4 += 4) {
+        float ks[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop_p > 0.f) drop_scale4(seed, (uint64_t)(row * s.H + c * VEC + j4), drop_p, keep_scale, ks);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          r.v[j4 + j] = static_cast<T>(one(static_cast<float>(a.v[j4 + j]), static_cast<float>(d.v[j4 + j]), ks[j]));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float ks = drop_p > 0.f ? drop_scale(seed, (uint64_t)(row * s.H + c * VEC + j), drop_p, keep_scale) : 1.f;
+        r.v[j] = static_cast<T>(one(static_cast<float>(a.v[j]), static_cast<float>(d.v[j]), ks));
+      }
+    }
     *reinterpret_cast<V*>(o + c * VEC) = r;
   }
-  for (int64_t h = nfull * VEC + lane; h < s.H; h += kWave)
-    o[h] = static_cast<T>(one(static_cast<float>(fr[h]), static_cast<float>(gr[h]), h));
+  for (int64_t h = nfull * VEC + lane; h < s.H; h += kWave) {
+    const float ks = drop_p > 0.f ? drop_scale(seed, (uint64_t)(row * s.H + h), drop_p, keep_scale) : 1.f;
+    o[h] = static_cast<T>(one(static_cast<float>(fr[h]), static_cast<float>(gr[h]), ks));
+  }
 }
 
 // mode: 0 = plain add, 1 = relu (+dropout): mask = out > 0, 2 = dropout only: mask = out != 0

@@ -202,17 +202,8 @@ __device__ __forceinline__ int64_t tiled_index(int b, int k, int nk) {
   return (((int64_t)(b >> 5) * nk + (k >> 5)) * 32 + (b & 31)) * 32 + (k & 31);
 }
 
-// Inter-layer dropout without mask tensors: keep(seed, element counter) is a pure function, evaluated in the
-// forward epilogue (to emit the masked copy the next layer's input GEMM reads) and again in the backward
-// epilogue of the layer below (to mask the incoming gradient).  Same splitmix64 counter hash as csrc/joint.hip.
-__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : inv_keep;
-}
+// Inter-layer dropout: drop_scale / drop_scale4 (common.h) -- evaluated in the forward epilogue (to emit the masked copy the
+// next layer's input GEMM reads) and again in the backward epilogue of the layer below (to mask the incoming gradient).
 
 // A launch ("wave") can advance SEVERAL independent recurrences at once: blockIdx.z selects a slot
 // (one LSTM layer working on its own timestep).  That is how a stack of layers is pipelined: layer l
@@ -830,11 +821,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
         *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
         if (w.ymask[slot]) {
           g4 mv;
+          float ks[4];
+          drop_scale4(w.seed, w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e, pd, inv_keep, ks);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
-            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
-          }
+          for (int q = 0; q < 4; ++q) mv[q] = static_cast<T>(static_cast<float>(hv[q]) * ks[q]);
           *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
         }
         if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
@@ -1064,11 +1054,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt(FwdSlots<T> w, in
         *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
         if (w.ymask[slot]) {
           g4 mv;
+          float ks[4];
+          drop_scale4(w.seed, w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e, pd, inv_keep, ks);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
-            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
-          }
+          for (int q = 0; q < 4; ++q) mv[q] = static_cast<T>(static_cast<float>(hv[q]) * ks[q]);
           *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
         }
         if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
@@ -1315,11 +1304,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
         *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
         if (w.ymask[slot]) {
           g4 mv;
+          float ks[4];
+          drop_scale4(w.seed, w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e, pd, inv_keep, ks);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
-            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
-          }
+          for (int q = 0; q < 4; ++q) mv[q] = static_cast<T>(static_cast<float>(hv[q]) * ks[q]);
           *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
         }
         if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
@@ -1563,11 +1551,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_dma(FwdSlots<T> w, i
         *reinterpret_cast<g4*>(w.c[slot] + so * (s + 1) + e) = cv;
         if (w.ymask[slot]) {
           g4 mv;
+          float ks[4];
+          drop_scale4(w.seed, w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e, pd, inv_keep, ks);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint64_t ctr = w.drop_base[slot] + (uint64_t)s * (uint64_t)so + (uint64_t)e + q;
-            mv[q] = static_cast<T>(static_cast<float>(hv[q]) * drop_scale(w.seed, ctr, pd, inv_keep));
-          }
+          for (int q = 0; q < 4; ++q) mv[q] = static_cast<T>(static_cast<float>(hv[q]) * ks[q]);
           *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
         }
         if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
@@ -1815,13 +1802,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
     if (ep) {
       const int ert = ul4 >> 4, ect = eb >> 4, ebl = eb & 15, eul = ul4 & 15;
       g4 vI, vF, vG, vO;
+      float ks[4] = {1.f, 1.f, 1.f, 1.f};
+      if (pd > 0.f) drop_scale4(w.seed, w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff, pd, inv_keep, ks);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float dy = static_cast<float>(dlv[q]);
-        if (pd > 0.f) {
-          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
-          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
-        }
+        float dy = static_cast<float>(dlv[q]) * ks[q];
         if (has_in)
           dy += red[(((0 * 2 + ert) * 2 + ect) * 16 + eul + q) * 17 + ebl] + red[(((1 * 2 + ert) * 2 + ect) * 16 + eul + q) * 17 + ebl];
         const frag& gv = q < 2 ? gv0 : gv1;
@@ -2156,13 +2141,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
     }
     if (ep) {
       g4 vI, vF, vG, vO;
+      float ks[4] = {1.f, 1.f, 1.f, 1.f};
+      if (pd > 0.f) drop_scale4(w.seed, w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff, pd, inv_keep, ks);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float dy = static_cast<float>(dlv[q]);
-        if (pd > 0.f) {
-          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
-          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
-        }
+        float dy = static_cast<float>(dlv[q]) * ks[q];
         dy += psum[q];
         const frag& gv = q < 2 ? gv0 : gv1;
         const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
@@ -2460,13 +2443,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt(BwdSlots<T> w, i
 #pragma unroll
       for (int q = 0; q < 4; ++q) dcs[q] = dv[q];
       g4 vI, vF, vG, vO;
+      float ks[4] = {1.f, 1.f, 1.f, 1.f};
+      if (pd > 0.f) drop_scale4(w.seed, w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff, pd, inv_keep, ks);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float dy = static_cast<float>(dlv[q]);
-        if (pd > 0.f) {
-          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
-          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
-        }
+        float dy = static_cast<float>(dlv[q]) * ks[q];
         dy += psum[q];
         const frag& gv = q < 2 ? gv0 : gv1;
         const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
@@ -2760,13 +2741,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2_bt_dma(BwdSlots<T> 
 #pragma unroll
       for (int q = 0; q < 4; ++q) dcs[q] = dv[q];
       g4 vI, vF, vG, vO;
+      float ks[4] = {1.f, 1.f, 1.f, 1.f};
+      if (pd > 0.f) drop_scale4(w.seed, w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff, pd, inv_keep, ks);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float dy = static_cast<float>(dlv[q]);
-        if (pd > 0.f) {
-          const uint64_t ctr = w.drop_base[slot] - (uint64_t)s * (uint64_t)so + (uint64_t)eoff + q;
-          dy *= drop_scale(w.seed, ctr, pd, inv_keep);
-        }
+        float dy = static_cast<float>(dlv[q]) * ks[q];
         dy += psum[q];
         const frag& gv = q < 2 ? gv0 : gv1;
         const float gi = static_cast<float>(gv[(q & 1) * 4 + 0]), gf = static_cast<float>(gv[(q & 1) * 4 + 1]);
