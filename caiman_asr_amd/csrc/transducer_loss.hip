@@ -43,7 +43,15 @@ struct LossParams {
   int batch;
 };
 
-constexpr int kPF = 4;  // prefetch distance (anti-diagonals) of the forward kernel
+// Prefetch distance (anti-diagonals) of the forward kernel = the length of a group of diagonals whose results are stored
+// together.  What it takes for the prefetch to exist at all (found in the ISA: the first version waited `vmcnt(0)` right
+// behind every load, 1.2 us per diagonal = the latency of a gather from the 5 GB logits): (1) the ring keeps RAW loaded
+// values and converts at use (a conversion at load time needs the data at load time); (2) the loads are unconditional,
+// from clamped addresses (a load under a per-lane condition is a branch with a full wait at its join); (3) no store
+// inside a group: loads and stores share `vmcnt` and complete out of order with each other, so with a store pending the
+// compiler answers every wait for a load with `vmcnt(0)` -- a lane keeps the group's results in registers and stores them
+// behind the group's last diagonal (one exposed load latency per kPF diagonals instead of one per diagonal).
+constexpr int kPF = 8;
 
 // ---------------------------------------------------------------------------
 // forward: grid (2, B); blockIdx.x = 0 -> alpha, 1 -> beta. blockDim = NT >= U'.
@@ -84,34 +92,32 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
     A* my_alpha = alpha + (int64_t)b * p.max_flen * p.max_glen;
     // cell (t,u) on diagonal s = t + u needs null(t-1,u) and emit(t,u-1).
     // ring slot k holds the raw operands for diagonal s with (s % kPF == k).
-    A xn[kPF], dn[kPF], xe[kPF], de[kPF];
+    T xn[kPF], xe[kPF];
+    A dn[kPF], de[kPF];
     const bool emit_is_star = (u > 0) && (lab_um1 == p.star_idx);  // emit(t,u-1) with label[u-1]==star
+    const int64_t xe_col = (u > 0 && !emit_is_star && active) ? lab_um1 : 0;
     auto issue = [&](int64_t s, int k) {
       const int64_t t = s - u;
-      xn[k] = 0; dn[k] = 0; xe[k] = 0; de[k] = 0;
-      if (active && t >= 0 && t < Tn) {
-        if (t > 0) {
-          const int64_t c = (t - 1) * stride + u;
-          xn[k] = static_cast<A>(xb[c * p.V + p.blank]);
-          dn[k] = db[c];
-        }
-        if (u > 0) {
-          const int64_t c = t * stride + (u - 1);
-          de[k] = db[c];
-          if (!emit_is_star) xe[k] = static_cast<A>(xb[c * p.V + lab_um1]);
-        }
-      }
+      const bool in = active && t >= 0 && t < Tn;
+      const int64_t cn = (in && t > 0) ? (t - 1) * stride + u : 0;        // cell 0 of the utterance: always there
+      const int64_t ce = (in && u > 0) ? t * stride + (u - 1) : 0;
+      xn[k] = xb[cn * p.V + p.blank];
+      dn[k] = db[cn];
+      de[k] = db[ce];
+      xe[k] = xb[ce * p.V + xe_col];
     };
     const int64_t nsteps = Tn + Un - 1;  // diagonals 0 .. nsteps-1
 #pragma unroll
     for (int k = 0; k < kPF; ++k) issue(1 + k, (1 + k) % kPF);
 
     A mine = 0;  // alpha(t,u) of the previous diagonal for this lane (t-1,u)
+    A hist[kPF];
     if (u == 0) my_alpha[0] = 0;
     buf0[u + 1] = (u == 0) ? (A)0 : (A)0;  // diagonal 0: only (0,0) is valid
     __syncthreads();
 
     for (int64_t s0 = 1; s0 < nsteps; s0 += kPF) {
+      unsigned stored = 0;
 #pragma unroll
       for (int k = 0; k < kPF; ++k) {
         const int64_t s = s0 + k;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
           const A left = prev[u];  // alpha(t, u-1) (slot u holds lane u-1's value)
           A a_null = 0, a_emit = 0;
           if (t > 0) {
-            const A lp = sub_or_nan<A>(xn[slot], dn[slot]);
+            const A lp = sub_or_nan<A>(static_cast<A>(xn[slot]), dn[slot]);
             const A nul = (u == 0) ? lp : (row_is_star ? star_lam : lp);
             a_null = mine + nul;
           }
@@ -136,35 +142,39 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
             if (emit_is_star) {
               em = dp;
             } else {
-              em = sub_or_nan<A>(xe[slot], de[slot]) + dp;
+              em = sub_or_nan<A>(static_cast<A>(xe[slot]), de[slot]) + dp;
               if (lab_um1 == p.eos_idx) em += frac_penalty<A>(eos_lam, (A)t, Tf);
             }
             a_emit = left + em;
           }
           val = (u == 0) ? a_null : (t == 0 ? a_emit : lse2<A>(a_null, a_emit));
-          my_alpha[t * p.max_glen + u] = val;
+          hist[k] = val;
+          stored |= 1u << k;
         }
         mine = val;
         cur[u + 1] = val;
         issue(s + kPF, slot);
         __syncthreads();
       }
+#pragma unroll
+      for (int k = 0; k < kPF; ++k)
+        if ((stored >> k) & 1u) my_alpha[(s0 + k - u) * p.max_glen + u] = hist[k];
     }
   } else {
     // ------------------------------ beta -----------------------------------
     A* my_beta = beta + (int64_t)b * p.max_flen * p.max_glen;
     // cell (t,u) on diagonal s = t + u needs null(t,u) and emit(t,u) (same cell).
-    A xn[kPF], xe[kPF], dd[kPF];
+    T xn[kPF], xe[kPF];
+    A dd[kPF];
     const bool emit_is_star = active && (u < Un - 1) && (lab_u == p.star_idx);
+    const int64_t xe_col = (active && u < Un - 1 && !emit_is_star) ? lab_u : 0;
     auto issue = [&](int64_t s, int k) {
       const int64_t t = s - u;
-      xn[k] = 0; xe[k] = 0; dd[k] = 0;
-      if (active && s >= 0 && t >= 0 && t < Tn) {
-        const int64_t c = t * stride + u;
-        dd[k] = db[c];
-        xn[k] = static_cast<A>(xb[c * p.V + p.blank]);
-        if (u < Un - 1 && !emit_is_star) xe[k] = static_cast<A>(xb[c * p.V + lab_u]);
-      }
+      const bool in = active && s >= 0 && t >= 0 && t < Tn;
+      const int64_t c = in ? t * stride + u : 0;                          // cell 0 of the utterance: always there
+      dd[k] = db[c];
+      xn[k] = xb[c * p.V + p.blank];
+      xe[k] = xb[c * p.V + xe_col];
     };
     const int64_t top = Tn + Un - 2;  // diagonal of the terminal cell
     // Walk diagonals top, top-1, ..., 0. Use j = top - s as the ascending counter
@@ -173,7 +183,9 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
     for (int k = 0; k < kPF; ++k) issue(top - k, k);
 
     A mine = 0;  // beta(t+1, u) for this lane
+    A hist[kPF];
     for (int64_t j0 = 0; j0 <= top; j0 += kPF) {
+      unsigned stored = 0;
 #pragma unroll
       for (int k = 0; k < kPF; ++k) {
         const int64_t j = j0 + k;
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
         const bool valid = active && t >= 0 && t < Tn;
         A val = mine;
         if (valid) {
-          const A lp_blank = sub_or_nan<A>(xn[k], dd[k]);
+          const A lp_blank = sub_or_nan<A>(static_cast<A>(xn[k]), dd[k]);
           const A nul = (u == 0) ? lp_blank : (row_is_star ? star_lam : lp_blank);
           if (t == Tn - 1 && u == Un - 1) {
             val = nul;  // transducer_loss.cu:228
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
               if (emit_is_star) {
                 em = dp;
               } else {
-                em = sub_or_nan<A>(xe[k], dd[k]) + dp;
+                em = sub_or_nan<A>(static_cast<A>(xe[k]), dd[k]) + dp;
                 if (lab_u == p.eos_idx) em += frac_penalty<A>(eos_lam, (A)t, Tf);
               }
             }
@@ -207,13 +219,17 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
               val = (t == Tn - 1) ? up + em : lse2<A>(mine + nul, up + em);
             }
           }
-          my_beta[t * p.max_glen + u] = val;
+          hist[k] = val;
+          stored |= 1u << k;
         }
         mine = val;
         cur[u + 1] = val;
         issue(s - kPF, k);
         __syncthreads();
       }
+#pragma unroll
+      for (int k = 0; k < kPF; ++k)
+        if ((stored >> k) & 1u) my_beta[(top - (j0 + k) - u) * p.max_glen + u] = hist[k];
     }
     if (u == 0) loss[b] = -mine;  // lane 0 finishes on cell (0,0): transducer_loss.cu:260-262
   }
