@@ -29,50 +29,23 @@ struct JointShape {
   int packed;
 };
 
-__device__ __forceinline__ bool locate_row(const JointShape& s, int64_t row, int& b, int64_t& t, int64_t& u) {
-  if (s.packed) {
-    int lo = 0, hi = (int)s.B - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (s.batch_offset[mid] > row) hi = mid; else lo = mid + 1;
-    }
-    b = lo;
-    const int64_t local = row - (b == 0 ? 0 : s.batch_offset[b - 1]);
-    const int64_t gl = s.g_len[b];
-    t = local / gl;
-    u = local - t * gl;
-    return true;
-  }
-  const int64_t per = s.T * s.U;
-  b = (int)(row / per);
-  const int64_t local = row - (int64_t)b * per;
-  t = local / s.U;
-  u = local - t * s.U;
-  return t < s.f_len[b] && u < s.g_len[b];
-}
-
+// One workgroup per (t, b): its four waves take the rows u = wave, wave + 4, ... of that frame.  (The first version gave
+// every wave one packed row and found (b, t, u) by a binary search over batch_offset: five dependent loads in front of
+// 1.5 KB of work per wave.)
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void joint_fwd_kernel(const T* __restrict__ f, const T* __restrict__ g,
                                                         JointShape s, int relu, float drop_p, uint64_t seed,
                                                         T* __restrict__ out) {
   using V = vecj<T, VEC>;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-  if (row >= s.total_rows) return;
-  int b; int64_t t, u;
-  const bool valid = locate_row(s, row, b, t, u);
-  T* o = out + row * s.H;
-  const int64_t nfull = s.H / VEC;
-  if (!valid) {  // padded layout, don't-care cell: -1 (training/tests/rnnt/test_model.py:57-60)
-    V m;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) m.v[j] = static_cast<T>(-1.f);
-    for (int64_t c = lane; c < nfull; c += kWave) *reinterpret_cast<V*>(o + c * VEC) = m;
-    for (int64_t h = nfull * VEC + lane; h < s.H; h += kWave) o[h] = static_cast<T>(-1.f);
-    return;
-  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwave = blockDim.x / kWave;
+  const int b = blockIdx.y;
+  const int64_t t = blockIdx.x;
+  const int64_t fl = s.f_len[b], gl = s.g_len[b];
+  if (s.packed && t >= fl) return;                         // the packed layout has no rows for this frame
+  const int64_t nu = s.packed ? gl : s.U;
+  const int64_t base = s.packed ? (b == 0 ? 0 : s.batch_offset[b - 1]) + t * gl : ((int64_t)b * s.T + t) * s.U;
   const T* fr = f + ((int64_t)b * s.T + t) * s.H;
-  const T* gr = g + ((int64_t)b * s.U + u) * s.H;
+  const int64_t nfull = s.H / VEC;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   // `ks`: 1 without dropout, else 0 (dropped) or 1 / (1 - p) (common.h drop_scale: one hash per four consecutive elements)
   auto one = [&](float a, float c, float ks) -> float {
@@ -82,31 +55,44 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T* __restrict__ f,
     if (relu) v = (v > 0.f || v != v) ? v : 0.f;
     return drop_p > 0.f ? (ks == 0.f ? 0.f : v * ks) : v;
   };
-  for (int64_t c = lane; c < nfull; c += kWave) {
-    const V a = *reinterpret_cast<const V*>(fr + c * VEC);
-    const V d = *reinterpret_cast<const V*>(gr + c * VEC);
-    V r;
-    if constexpr (VEC % 4 == 0) {
+  for (int64_t u = wave; u < nu; u += nwave) {
+    const int64_t row = base + u;
+    T* o = out + row * s.H;
+    if (!(t < fl && u < gl)) {  // padded layout, don't-care cell: -1 (training/tests/rnnt/test_model.py:57-60)
+      V m;
 #pragma unroll
-      for (int j4 = 0; j4 < VEC; j4 += 4) {
-        float ks[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop_p > 0.f) drop_scale4(seed, (uint64_t)(row * s.H + c * VEC + j4), drop_p, keep_scale, ks);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          r.v[j4 + j] = static_cast<T>(one(static_cast<float>(a.v[j4 + j]), static_cast<float>(d.v[j4 + j]), ks[j]));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float ks = drop_p > 0.f ? drop_scale(seed, (uint64_t)(row * s.H + c * VEC + j), drop_p, keep_scale) : 1.f;
-        r.v[j] = static_cast<T>(one(static_cast<float>(a.v[j]), static_cast<float>(d.v[j]), ks));
-      }
+      for (int j = 0; j < VEC; ++j) m.v[j] = static_cast<T>(-1.f);
+      for (int64_t c = lane; c < nfull; c += kWave) *reinterpret_cast<V*>(o + c * VEC) = m;
+      for (int64_t h = nfull * VEC + lane; h < s.H; h += kWave) o[h] = static_cast<T>(-1.f);
+      continue;
     }
-    *reinterpret_cast<V*>(o + c * VEC) = r;
-  }
-  for (int64_t h = nfull * VEC + lane; h < s.H; h += kWave) {
-    const float ks = drop_p > 0.f ? drop_scale(seed, (uint64_t)(row * s.H + h), drop_p, keep_scale) : 1.f;
-    o[h] = static_cast<T>(one(static_cast<float>(fr[h]), static_cast<float>(gr[h]), ks));
+    const T* gr = g + ((int64_t)b * s.U + u) * s.H;
+    for (int64_t c = lane; c < nfull; c += kWave) {
+      const V a = *reinterpret_cast<const V*>(fr + c * VEC);
+      const V d = *reinterpret_cast<const V*>(gr + c * VEC);
+      V r;
+      if constexpr (VEC % 4 == 0) {
+#pragma unroll
+        for (int j4 = 0; j4 < VEC; j4 += 4) {
+          float ks[4] = {1.f, 1.f, 1.f, 1.f};
+          if (drop_p > 0.f) drop_scale4(seed, (uint64_t)(row * s.H + c * VEC + j4), drop_p, keep_scale, ks);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            r.v[j4 + j] = static_cast<T>(one(static_cast<float>(a.v[j4 + j]), static_cast<float>(d.v[j4 + j]), ks[j]));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float ks = drop_p > 0.f ? drop_scale(seed, (uint64_t)(row * s.H + c * VEC + j), drop_p, keep_scale) : 1.f;
+          r.v[j] = static_cast<T>(one(static_cast<float>(a.v[j]), static_cast<float>(d.v[j]), ks));
+        }
+      }
+      *reinterpret_cast<V*>(o + c * VEC) = r;
+    }
+    for (int64_t h = nfull * VEC + lane; h < s.H; h += kWave) {
+      const float ks = drop_p > 0.f ? drop_scale(seed, (uint64_t)(row * s.H + h), drop_p, keep_scale) : 1.f;
+      o[h] = static_cast<T>(one(static_cast<float>(fr[h]), static_cast<float>(gr[h]), ks));
+    }
   }
 }
 
@@ -183,8 +169,8 @@ extern "C" int caiman_joint_forward(const void* f, const void* g, const int32_t*
   CAIMAN_CHECK(packed || total_rows == B * T * U, "joint_forward: padded output must have B*T*U rows");
   if (total_rows == 0) return CAIMAN_OK;
   CAIMAN_CHECK(f && g && f_len && g_len && out, "joint_forward: null pointer");
-  const int64_t nblk = (total_rows + 3) / 4;
-  CAIMAN_CHECK(nblk < ((int64_t)1 << 31), "joint_forward: too many rows for one launch");
+  CAIMAN_CHECK(B <= 65535 && T < ((int64_t)1 << 31), "joint_forward: batch / frame count too large for one launch");
+  const dim3 grid((unsigned)T, (unsigned)B);
   JointShape s{f_len, g_len, batch_offset, B, T, U, H, total_rows, packed};
   hipStream_t st = static_cast<hipStream_t>(stream);
   return CAIMAN_DISPATCH(dtype, "joint_forward", [&]() -> int {
@@ -195,10 +181,10 @@ extern "C" int caiman_joint_forward(const void* f, const void* g, const int32_t*
     auto gp = static_cast<const scalar_t*>(g);
     auto op = static_cast<scalar_t*>(out);
     if (aligned)
-      hipLaunchKernelGGL((joint_fwd_kernel<scalar_t, VEC>), dim3((unsigned)nblk), dim3(256), 0, st, fp, gp, s, relu,
+      hipLaunchKernelGGL((joint_fwd_kernel<scalar_t, VEC>), grid, dim3(256), 0, st, fp, gp, s, relu,
                          (float)dropout_p, seed, op);
     else
-      hipLaunchKernelGGL((joint_fwd_kernel<scalar_t, 1>), dim3((unsigned)nblk), dim3(256), 0, st, fp, gp, s, relu,
+      hipLaunchKernelGGL((joint_fwd_kernel<scalar_t, 1>), grid, dim3(256), 0, st, fp, gp, s, relu,
                          (float)dropout_p, seed, op);
     return check_launch("caiman_joint_forward");
   });
