@@ -57,19 +57,24 @@ __global__ __launch_bounds__(NW* kWave) void lse_rows_kernel(const T* __restrict
 
   // ---- pass 1: max -----------------------------------------------------------
   if constexpr (CACHE > 0) {
+    // all CACHE loads first, unconditionally per lane (a lane past the row's end loads the row's last chunk again and
+    // discards it): under the per-lane condition `c < nfull` every load was a branch with a `vmcnt(0)` of its own behind
+    // it -- one 16-byte load in flight per wave (seen in the ISA)
+    V raw[CACHE] = {};
+    if (nfull > 0) {
+#pragma unroll
+      for (int k = 0; k < CACHE; ++k) {
+        const int64_t c = tid + (int64_t)k * NT;
+        raw[k] = *reinterpret_cast<const V*>(row + (c < nfull ? c : nfull - 1) * VEC);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < CACHE; ++k) {
-      const int64_t c = tid + (int64_t)k * NT;
-      if (c < nfull) {
-        V v = *reinterpret_cast<const V*>(row + c * VEC);
+      const bool own = tid + (int64_t)k * NT < nfull;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          vals[k * VEC + j] = static_cast<A>(v.v[j]);
-          m = nan_max(m, vals[k * VEC + j]);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) vals[k * VEC + j] = lowest;
+      for (int j = 0; j < VEC; ++j) {
+        vals[k * VEC + j] = own ? static_cast<A>(raw[k].v[j]) : lowest;
+        m = nan_max(m, vals[k * VEC + j]);
       }
     }
   }
