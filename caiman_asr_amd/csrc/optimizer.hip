@@ -154,21 +154,32 @@ __global__ __launch_bounds__(kOptThreads) void lamb_stage2_kernel(LambArgs a, co
   float4* p4 = reinterpret_cast<float4*>(a.p + s);
   float4* g4 = reinterpret_cast<float4*>(a.g + s);
   float4* e4 = a.ema ? reinterpret_cast<float4*>(a.ema + s) : nullptr;
-  for (int i = threadIdx.x; i < n / 4; i += kOptThreads) {
-    float4 p = p4[i];
-    if (apply) {
-      const float4 u = g4[i];
-      p.x -= r * u.x; p.y -= r * u.y; p.z -= r * u.z; p.w -= r * u.w;
-      p4[i] = p;
+  // all of an iteration's loads first, then its stores: with the EMA load behind the parameter store (loads and stores share
+  // `vmcnt`) every iteration waited for a store acknowledgement in its middle.  `apply` and the EMA pointer are uniform:
+  // one straight-line loop per combination.
+  auto sweep = [&](auto apply_tag, auto ema_tag) {
+    constexpr bool APPLY = decltype(apply_tag)::value, EMA = decltype(ema_tag)::value;
+    for (int i = threadIdx.x; i < n / 4; i += kOptThreads) {
+      float4 p = p4[i];
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f), e = u;
+      if constexpr (APPLY) u = g4[i];
+      if constexpr (EMA) e = e4[i];
+      if constexpr (APPLY) {
+        p.x -= r * u.x; p.y -= r * u.y; p.z -= r * u.z; p.w -= r * u.w;
+      }
+      if constexpr (EMA) {
+        e.x = d * e.x + (1.f - d) * p.x; e.y = d * e.y + (1.f - d) * p.y;
+        e.z = d * e.z + (1.f - d) * p.z; e.w = d * e.w + (1.f - d) * p.w;
+      }
+      if constexpr (APPLY) p4[i] = p;
+      if constexpr (EMA) e4[i] = e;
+      if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (e4) {
-      float4 e = e4[i];
-      e.x = d * e.x + (1.f - d) * p.x; e.y = d * e.y + (1.f - d) * p.y;
-      e.z = d * e.z + (1.f - d) * p.z; e.w = d * e.w + (1.f - d) * p.w;
-      e4[i] = e;
-    }
-    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  };
+  using yes = std::true_type;
+  using no = std::false_type;
+  if (apply) { if (e4) sweep(yes{}, yes{}); else sweep(yes{}, no{}); }
+  else { if (e4) sweep(no{}, yes{}); else sweep(no{}, no{}); }
   for (int i = (n / 4) * 4 + threadIdx.x; i < n; i += kOptThreads) {
     float p = a.p[s + i];
     if (apply) { p -= r * a.g[s + i]; a.p[s + i] = p; }
