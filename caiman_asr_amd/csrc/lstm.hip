@@ -1174,6 +1174,25 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
           (__attribute__((address_space(3))) void*)(gb + (wave * 32 + i * 16) * 32), 16, 0, 0);
     }
   };
+  // the same 18 pieces one at a time (p = 0 .. 15: piece i = p & 7 of stage p >> 3; 16, 17: the pre-activations), for the
+  // tile-steps that issue them BETWEEN the MFMA blocks: a piece costs its wave 60 - 185 cycles of issue (guide, cycle table),
+  // eighteen in a row in front of the first MFMA were 0.5 - 1 us of every 4 us tile-step with the matrix cores idle
+  auto gather_piece = [&](T* b0, int s_, int bt_, int sg_, int btg_, int p) {
+    if (p < 8 * NST) {
+      const int q = p >> 3, i = p & 7;
+      const int bl = wave + 4 * i, b = bt_ * 32 + bl, bs = b < B ? b : B - 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(w.y[slot] + so * s_ + (int64_t)bs * H + q * 512 + lane * 8),
+          (__attribute__((address_space(3))) void*)(b0 + q * 32 * LDW + bl * LDW), 16, 0, 16);
+    } else {
+      const int i = p - 8 * NST;
+      T* gb = b0 + NST * 32 * LDW;
+      const int bl = i * 16 + (lane >> 2), b = btg_ * 32 + bl, bs = b < B ? b : B - 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(w.g[slot] + go * sg_ + ((int64_t)bs * H + u0) * 4 + (lane & 3) * 8),
+          (__attribute__((address_space(3))) void*)(gb + (wave * 32 + i * 16) * 32), 16, 0, 0);
+    }
+  };
 
   int s = 0, bt = 0;
   bool have = false, aborted = false;     // have: this tile-step's operands were gathered during the previous one
@@ -1223,7 +1242,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
     if (prof && !ready) ++n_notready;
 #endif
     BT_MARK(0)
-    gather(n0, ready ? s_n : s, ready ? bt_n : bt, more ? s_n : s, more ? bt_n : bt);     // flies under the MFMAs below
+    const int gs_ = ready ? s_n : s, gbt_ = ready ? bt_n : bt, gsg_ = more ? s_n : s, gbtg_ = more ? bt_n : bt;
+#ifdef BT_GATHER_UPFRONT
+    gather(n0, gs_, gbt_, gsg_, gbtg_);     // flies under the MFMAs below
+#endif
     f32x4 acc[2][2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -1241,6 +1263,19 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_bt_dma(FwdSlots<T> w
       }
 #pragma unroll
       for (int nb = 0; nb < NB_; ++nb) {
+#ifndef BT_GATHER_UPFRONT
+        {   // this block's share of the next tile-step's gather: 18 pieces over NST * NB_ blocks of 16 MFMAs
+#ifndef BT_GATHER_BLOCKS
+#define BT_GATHER_BLOCKS (NST * NB_)
+#endif
+          constexpr int NBLK = BT_GATHER_BLOCKS, NP = 8 * NST + 2;
+          const int blk = q * NB_ + nb;
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if (p * NBLK / NP == blk) gather_piece(n0, gs_, gbt_, gsg_, gbtg_, p);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         if (nb + 1 < NB_) {
 #pragma unroll
           for (int i = 0; i < KB; ++i) {
