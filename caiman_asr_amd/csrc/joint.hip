@@ -126,7 +126,34 @@ __global__ __launch_bounds__(128) void joint_bwd_kernel(const T* __restrict__ dh
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    if (live) {
+    if (live && fullvec && mode) {
+      // four rows' loads in flight, then their terms added in row order (the sum is the one-row-at-a-time loop's, bit for bit)
+      const int64_t row0 = REDUCE_U ? base + i * ustride : base + i;
+      const int64_t rstep = (REDUCE_U ? 1 : ustride) * s.H;
+      const T* pd = dh + row0 * s.H + h0;
+      const T* ph = ho + row0 * s.H + h0;
+      int64_t k = 0;
+      for (; k + 4 <= nred; k += 4) {
+        V a[4], m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[q] = *reinterpret_cast<const V*>(pd + (k + q) * rstep);
+          m[q] = *reinterpret_cast<const V*>(ph + (k + q) * rstep);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            acc[j] += masked<T>(static_cast<float>(a[q].v[j]), static_cast<float>(m[q].v[j]), mode, scale);
+      }
+      for (; k < nred; ++k) {
+        const V a = *reinterpret_cast<const V*>(pd + k * rstep);
+        const V m = *reinterpret_cast<const V*>(ph + k * rstep);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          acc[j] += masked<T>(static_cast<float>(a.v[j]), static_cast<float>(m.v[j]), mode, scale);
+      }
+    } else if (live) {
       for (int64_t k = 0; k < nred; ++k) {
         const int64_t row = REDUCE_U ? base + i * ustride + k : base + k * ustride + i;
         const T* pd = dh + row * s.H + h0;
