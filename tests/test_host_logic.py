@@ -363,3 +363,39 @@ def test_profile_kernel_names_map_to_their_rows():
     assert ps.short("_ZN6caiman12_GLOBAL__N_116proj_gemm_kernelIDF16bLi128ELi128ELi2ELi8ELi1ELb0EEEvNS0_9ProjBatchE") == "proj_gemm_kernel"
     assert ps.short("Cijk_Ailk_Bjlk_BBS_BH_Bias_HA_S_SAV_UserArgs_MT256x256x32") == "library_gemm"
     assert ps.short("void at::native::vectorized_elementwise_kernel<4>") is None
+
+
+def test_weight_gradient_plan_and_cost_model_are_host_logic():
+    """caiman_wgrad_tn_plan / _estimate_us (csrc/joint_wgrad.hip) run on the host: slice counts follow the 256-CU round
+    quantisation, the estimate carries the per-round fixed cost, unsupported shapes return 0 / a negative estimate."""
+    import ctypes
+
+    import torch
+
+    from caiman_asr_amd import _lib
+
+    lib = _lib.lib()
+    bf16 = _lib.dtype_tag(torch.bfloat16)
+    per = ctypes.c_int64(0)
+
+    def plan(M, N, K, P=1):
+        s = lib.caiman_wgrad_tn_plan(M, N, K, P, bf16, ctypes.byref(per))
+        return s, per.value
+
+    assert plan(304000, 8704, 768) == (5, 60800)            # joint projection: 102 tiles x 5 = 510 workgroups, two rounds
+    assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 768, bf16, ctypes.byref(per)) == 5 and per.value == 60800
+    s, rows = plan(304000, 17408, 1024)                      # large-196M: 272 tiles, one slice would be 1.06 rounds
+    assert s >= 8 and s * rows <= 304000 and rows % 32 == 0 and 304000 - s * rows < 32 * s
+    assert plan(8896, 4096, 1024, 6) == (2, 4448)            # six LSTM layers: 384 tiles x 2 = 3 rounds, no rows left over
+    for M, N, K, P in [(100, 512, 512, 1), (4096, 500, 512, 1), (4096, 512, 240, 1), (4096, 512, 512, 0)]:
+        assert plan(M, N, K, P)[0] == 0
+        assert lib.caiman_wgrad_tn_estimate_us(M, N, K, P, bf16) < 0
+    assert lib.caiman_wgrad_tn_plan(4096, 512, 512, 1, _lib.dtype_tag(torch.float32), ctypes.byref(per)) == 0
+    est = lib.caiman_wgrad_tn_estimate_us
+    # measured 3.28-3.42 ms / 572 us / 159 us (tools/joint_gemm_bench.py, tools/wgrad_tn_bench.py): the model within 20 %
+    assert 2800 < est(304000, 8704, 768, 1, bf16) < 3900
+    assert 450 < est(8896, 4096, 1024, 6, bf16) < 690
+    assert 130 < est(17792, 4096, 1024, 1, bf16) < 190
+    # five layers fill 2.5 rounds: the model prices them above the library's 0.8 PF/s, and the caller keeps the library
+    flops = 2.0 * 5 * 8896 * 4096 * 1024
+    assert est(8896, 4096, 1024, 5, bf16) * 1e-6 > flops / 0.8e15
