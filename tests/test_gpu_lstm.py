@@ -457,3 +457,34 @@ def test_process_falls_back_to_per_timestep_kernels_after_a_handoff_timeout():
         lib.caiman_lstm_resident_set_failures(prev)
     _, n = _run_stack(m, x, h0, c0, w, torch.bfloat16, 1)
     assert n > 0 and lib.caiman_lstm_resident_failures() == prev
+
+
+def test_dropout_hash_statistics_per_group_position_and_across_offsets():
+    """csrc/common.h drop_scale4: one 64-bit hash serves four consecutive elements (16 bits each).  On 4 M elements: the
+    drop rate of EVERY position inside a group is p (3 sigma of a binomial + the 1 / 65536 threshold step), the four
+    positions of a group are uncorrelated, so are neighbouring groups and masks of different seeds, and a mask generated
+    from an offset that is not a multiple of four equals the matching window of the aligned one (per-element fallback)."""
+    from caiman_asr_amd import _lib
+
+    n, seed = 4 * 1024 * 1024, 0x1234_5678_9ABC_DEF
+    tag = _lib.dtype_tag(torch.bfloat16)
+
+    def mask(seed_, base, count, p_):
+        mk = torch.empty(count, device=DEV, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().caiman_lstm_dropout_mask(_lib.ptr(mk), count, seed_, base, p_, tag, _lib.stream()))
+        return mk == 0
+
+    for p_ in (0.1, 0.3):
+        d = mask(seed, 0, n, p_).view(-1, 4).float()
+        sigma = (p_ * (1 - p_) / d.shape[0]) ** 0.5
+        rates = d.mean(0)
+        assert ((rates - p_).abs() < 4 * sigma + 2.0 / 65536).all(), rates
+        c = torch.corrcoef(d.t())
+        assert (c - torch.eye(4, device=DEV)).abs().max() < 5e-3, c
+        lag = torch.corrcoef(torch.stack([d[:-1, 3], d[1:, 0]]))[0, 1]
+        assert lag.abs() < 5e-3
+        other = mask(seed + 1, 0, n, p_).view(-1, 4).float()
+        assert torch.corrcoef(torch.stack([d[:, 0], other[:, 0]]))[0, 1].abs() < 5e-3
+    whole = mask(seed, 0, 4096, 0.3)
+    for off in (1, 2, 3, 7):
+        assert torch.equal(mask(seed, off, 1024, 0.3), whole[off:off + 1024])
