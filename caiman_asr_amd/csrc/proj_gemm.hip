@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb
   constexpr int ABLK = BM / 8 / NW, WBLK = BN / 8 / NW;   // 8-row blocks (1 KB, one DMA instruction) per wave and operand
   static_assert(KS == 1 || (KS == 2 && NS == 2 && BM == 128 && BN == 128 && NW == 8), "K split: 128 x 128 tiles, two stages");
   __shared__ __attribute__((aligned(1024))) T gA0[BM * BK], gA1[BM * BK], gW0[BN * BK], gW1[BN * BK];
-  __shared__ __attribute__((aligned(1024))) T lA2[NS == 3 ? BM * BK : 8], lW2[NS == 3 ? BN * BK : 8];   // third stage
+  __shared__ __attribute__((aligned(1024))) T lA2[NS >= 3 ? BM * BK : 8], lW2[NS >= 3 ? BN * BK : 8];   // third stage
+  __shared__ __attribute__((aligned(1024))) T lA3[NS == 4 ? BM * BK : 8], lW3[NS == 4 ? BN * BK : 8];   // fourth stage
   __shared__ __attribute__((aligned(1024))) T hA0[KS == 2 ? BM * BK : 8], hA1[KS == 2 ? BM * BK : 8], hW0[KS == 2 ? BN * BK : 8],
       hW1[KS == 2 ? BN * BK : 8];                                                                        // second K group
 
@@ -210,19 +211,65 @@ __global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
+  } else if constexpr (NS == 4) {
+    // ring of four stages, three in flight (csrc/joint_gemm.hip's loop): the backward ticks' products have K = 4H and about
+    // one 128 x 128 tile per CU, so the step time is what the L2 -> LDS feed delivers once its latency is covered
+    static_assert(ABLK + WBLK == 4, "vmcnt immediates below: four DMA instructions per wave and stage");
+    auto steady = [&](const T* cA, const T* cW, T* nA, T* nW, int ks) {
+      __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): stages ks + 1, ks + 2 may still fly
+      __builtin_amdgcn_s_barrier();
+      issue(nA, nW, (ks + 3) * BK);
+      compute(cA, cW);
+    };
+    auto drain = [&](const T* cA, const T* cW, auto w) {
+      __builtin_amdgcn_s_waitcnt(decltype(w)::value);
+      __builtin_amdgcn_s_barrier();
+      compute(cA, cW);
+    };
+    using w8 = std::integral_constant<int, 0x0078>;
+    using w4 = std::integral_constant<int, 0x0074>;
+    using w0 = std::integral_constant<int, 0x0070>;
+    issue(lA0, lW0, 0);
+    issue(lA1, lW1, BK);
+    issue(lA2, lW2, 2 * BK);             // the launcher sends K < 256 elsewhere: at least four steps
+    int ks = 0;
+    for (; ks + 7 <= nk; ks += 4) {
+      steady(lA0, lW0, lA3, lW3, ks);
+      steady(lA1, lW1, lA0, lW0, ks + 1);
+      steady(lA2, lW2, lA1, lW1, ks + 2);
+      steady(lA3, lW3, lA2, lW2, ks + 3);
+    }
+    switch (nk - ks) {                   // 3 .. 6 steps left, the current one in buffer 0
+      case 3:
+        drain(lA0, lW0, w8{}); drain(lA1, lW1, w4{}); drain(lA2, lW2, w0{});
+        break;
+      case 4:
+        steady(lA0, lW0, lA3, lW3, ks);
+        drain(lA1, lW1, w8{}); drain(lA2, lW2, w4{}); drain(lA3, lW3, w0{});
+        break;
+      case 5:
+        steady(lA0, lW0, lA3, lW3, ks); steady(lA1, lW1, lA0, lW0, ks + 1);
+        drain(lA2, lW2, w8{}); drain(lA3, lW3, w4{}); drain(lA0, lW0, w0{});
+        break;
+      default:
+        steady(lA0, lW0, lA3, lW3, ks); steady(lA1, lW1, lA0, lW0, ks + 1); steady(lA2, lW2, lA1, lW1, ks + 2);
+        drain(lA3, lW3, w8{}); drain(lA0, lW0, w4{}); drain(lA1, lW1, w0{});
+        break;
+    }
   } else {
     // three stages, two of them in flight while the third is multiplied: with one workgroup per CU (the 256 x 128 tile
     // fills the LDS) a single stage in flight does not cover the load latency (~2 us under load).  One barrier per
     // step: behind it every wave's share of stage ks has landed (each waited for its own DMAs, all but the youngest
     // stage's) and every wave has finished multiplying stage ks - 1, whose buffer the DMAs of stage ks + 2 now overwrite.
     // A bare s_barrier: __syncthreads() carries a fence that would drain the DMAs in flight.
-    static_assert(ABLK + WBLK == 12 || ABLK + WBLK == 8 || NS == 2, "vmcnt immediates below");
+    static_assert(ABLK + WBLK == 12 || ABLK + WBLK == 8 || ABLK + WBLK == 4 || NS == 2, "vmcnt immediates below");
     auto phase = [&](const T* cA, const T* cW, T* nA, T* nW, int ks) {
       // s_waitcnt through the builtin (the compiler's own wait-count bookkeeping sees it; an asm wait it would follow with
       // a vmcnt(0) of its own before the first LDS read).  simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 0 << 8.
       if (ks + 1 < nk) {
         if constexpr (ABLK + WBLK == 12) __builtin_amdgcn_s_waitcnt(0x007C);   // vmcnt(12) lgkmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0x0078);                               // vmcnt(8) lgkmcnt(0)
+        else if constexpr (ABLK + WBLK == 8) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0074);                               // vmcnt(4) lgkmcnt(0)
       } else {
         __builtin_amdgcn_s_waitcnt(0x0070);                                    // vmcnt(0) lgkmcnt(0)
       }
@@ -236,7 +283,8 @@ __global__ __launch_bounds__(64 * NW * KS, 1) void proj_gemm_kernel(ProjBatch pb
     // stays exact across the loop (a conditional wait or issue makes it fall back to vmcnt(0) before the LDS reads)
     auto steady = [&](const T* cA, const T* cW, T* nA, T* nW, int ks) {
       if constexpr (ABLK + WBLK == 12) __builtin_amdgcn_s_waitcnt(0x007C);
-      else __builtin_amdgcn_s_waitcnt(0x0078);
+      else if constexpr (ABLK + WBLK == 8) __builtin_amdgcn_s_waitcnt(0x0078);
+      else __builtin_amdgcn_s_waitcnt(0x0074);
       __builtin_amdgcn_s_barrier();
       issue(nA, nW, (ks + 2) * BK);
       compute(cA, cW);
@@ -369,8 +417,13 @@ extern "C" int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n, in
   // workgroup per CU: 67 / 82 (4 waves, two LDS stages), 63 / 68 (three stages), 52 / 73 (8 waves).  A K step of one
   // workgroup takes 0.55 - 1 us whatever the tile (DMA issue -> LDS reads -> MFMAs -> wait for the next stage is one
   // serial chain per wave): more waves per CU overlap more of it, fewer operand bytes per flop do not help; 64 x 128
-  // tiles (three workgroups per CU) land on the same 53 us.
+  // tiles (three workgroups per CU) land on the same 53 us.  Round 3: 128 x 128 tiles, 8 waves, one workgroup per CU with a
+  // ring of three (tile 9) or four (tile 10) stages: 53.4 / 45.4 and 51.0 / 44.8 us; in the training step, where the
+  // operands are cold, the four-stage ring on the backward ticks is worth 0.35 ms per step against the K split (tile 8).
   if (tile == 0) tile = 5;
+  if (tile == 10)  // the four-stage ring needs four 64-deep steps
+    for (int i = 0; i < n; ++i)
+      if (problems[i].K < 256) tile = 5;
   if (tile == 8)   // the in-workgroup K split needs an even number of 64-deep steps per half
     for (int i = 0; i < n; ++i)
       if (problems[i].K % 256 != 0 || problems[i].a_kseg % 128 != 0) tile = 5;
@@ -379,12 +432,16 @@ extern "C" int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n, in
          : tile == 3 ? launch_proj<bf16_t, 256, 128, 3, 4>(problems, n, s)
          : tile == 4 ? launch_proj<bf16_t, 256, 128, 2, 8>(problems, n, s)
          : tile == 5 ? launch_proj<bf16_t, 128, 128, 2, 8>(problems, n, s)
-         : tile == 8 ? launch_proj<bf16_t, 128, 128, 2, 8, 2>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
+         : tile == 8 ? launch_proj<bf16_t, 128, 128, 2, 8, 2>(problems, n, s)
+         : tile == 9 ? launch_proj<bf16_t, 128, 128, 3, 8>(problems, n, s)
+         : tile == 10 ? launch_proj<bf16_t, 128, 128, 4, 8>(problems, n, s) : launch_proj<bf16_t, 128, 128, 2, 4>(problems, n, s);
   return tile == 1 ? launch_proj<f16_t, 256, 128, 2, 4>(problems, n, s)
        : tile == 3 ? launch_proj<f16_t, 256, 128, 3, 4>(problems, n, s)
        : tile == 4 ? launch_proj<f16_t, 256, 128, 2, 8>(problems, n, s)
        : tile == 5 ? launch_proj<f16_t, 128, 128, 2, 8>(problems, n, s)
-       : tile == 8 ? launch_proj<f16_t, 128, 128, 2, 8, 2>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
+       : tile == 8 ? launch_proj<f16_t, 128, 128, 2, 8, 2>(problems, n, s)
+       : tile == 9 ? launch_proj<f16_t, 128, 128, 3, 8>(problems, n, s)
+         : tile == 10 ? launch_proj<f16_t, 128, 128, 4, 8>(problems, n, s) : launch_proj<f16_t, 128, 128, 2, 4>(problems, n, s);
 }
 
 // One timestep of one LSTM layer for n rows as ONE launch (CellArgs above).  X [n][ldx_in] holds [x_t | h_{t-1}] rows,

@@ -34,8 +34,10 @@ EARLY_WGRAD = int(__import__("os").environ.get("CAIMAN_EARLY_WGRAD", "1")) != 0
 # projection kernel (csrc/proj_gemm.hip) instead of 2-3 library calls; shapes outside its geometry keep the library path
 PROJ = int(__import__("os").environ.get("CAIMAN_PROJ_GEMM", "1")) != 0
 PROJ_TILE = int(__import__("os").environ.get("CAIMAN_PROJ_TILE", "0"))
-# backward ticks (K = 4H, about one 128 x 128 tile per CU): the variant whose workgroup splits K between two wave groups
-PROJ_TILE_BWD = int(__import__("os").environ.get("CAIMAN_PROJ_TILE_BWD", "8"))
+# backward ticks (K = 4H, about one 128 x 128 tile per CU): the variant with a ring of four LDS stages, three in flight
+# (tile 10).  In the step 27.19-27.38 -> 26.85-26.97 ms against tile 8 (the workgroup splits K between two wave groups, two
+# stages each: 47.5 vs 44.8 us in tools/proj_gemm_bench.py, more in the step where the operands are cold)
+PROJ_TILE_BWD = int(__import__("os").environ.get("CAIMAN_PROJ_TILE_BWD", "10"))
 IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # one launch for all operand images of the weights
 # the layers' weight gradients dG^T . x / dG^T . h_prev on the transposed-read kernel (csrc/joint_wgrad.hip, fp32 results)
 # instead of the library's transposed-A GEMMs; shapes outside its geometry (K = 240 of layer 0) keep the library

@@ -40,7 +40,7 @@ def _tol(ref, dt, K):
     return (half_ulp + K * 2.0 ** -24) * float(ref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 8, 9, 10])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,bias", [(512, 4096, 1024, True), (224, 512, 256, True), (37, 256, 128, False),
                                         (1, 128, 128, True), (300, 1024, 4096, False),
@@ -59,7 +59,7 @@ def test_single_problem_matches_fp32_product(M, N, K, bias, dt, tile):
     assert bool((c[M] == 7.0).all()), "rows past M must not be written"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 8, 9, 10])
 def test_grouped_launch_with_stacked_views(tile):
     """Several problems of different K in one launch, among them the StackTime read (A rows gather f frames) and the
     StackTime scatter (C columns go to f frames): what one pipeline tick of encoder_pipe.py issues."""

@@ -60,7 +60,7 @@ def main():
         return a, w, b, c
 
     # ---- agreement --------------------------------------------------------------------------------------------
-    for tile in (2, 5, 8):
+    for tile in (2, 5, 8, 9, 10):
         for (M, N, K) in ((512, 4096, 1024), (1024, 4096, 1024), (224, 4096, 2048), (512, 1024, 4096), (37, 256, 128), (300, 256, 256), (64, 128, 384), (64, 128, 640)):
             a, w, b, c = mk(M, N, K)
             run([problem(a, w, b, c, M, N, K)], tile)
@@ -107,7 +107,7 @@ def main():
         torch.addmm(fw[1][2], fw[1][0], wts[1], out=fw[1][3])
         torch.baddbmm(bb, Xb, Wb, out=Ob)
 
-    for tile in ((args.tile,) if args.tile else (2, 5, 8)):
+    for tile in ((args.tile,) if args.tile else (2, 5, 8, 9, 10)):
         us = timeit(lambda: run(probs, tile))
         print(f"forward tick, grouped kernel tile {tile}: {us:.1f} us = {flops / us / 1e6:.0f} TFLOP/s", flush=True)
     us = timeit(lib_tick)
@@ -124,7 +124,7 @@ def main():
         for a, w, b, c in bw:
             torch.matmul(a, w.t(), out=c)
 
-    for tile in ((args.tile,) if args.tile else (2, 5, 8)):
+    for tile in ((args.tile,) if args.tile else (2, 5, 8, 9, 10)):
         us = timeit(lambda: run(probs, tile))
         print(f"backward tick, grouped kernel tile {tile}: {us:.1f} us = {flops / us / 1e6:.0f} TFLOP/s", flush=True)
     us = timeit(lib_tick_b)
