@@ -154,6 +154,7 @@ _SIGS = {
     "caiman_wgrad_tn_plan": ([I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_wgrad_tn_estimate_us": ([I64, I64, I64, I32, I32], ctypes.c_double),
     "caiman_wgrad_tn": ([P, I64, P, I64, P, I32, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
+    "caiman_wgrad_tn2": ([P, I64, P, I64, I32, P, I64, P, I64, I32, P, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_proj_gemm": ([P, I32, I32, I32, P], ctypes.c_int),
     "caiman_lstm_fused_fwd": ([P, P, P, P, P, I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_lstm_workspace_elems": ([I64, I64, I32], ctypes.c_int64),

@@ -69,7 +69,9 @@ template <typename T>
 __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Hm,
                                                                  float* __restrict__ slabs, int N, int K, int rows_per_slice,
                                                                  int tiles_k, int n_tiles, int slices, int64_t stride_y,
-                                                                 int64_t stride_h) {
+                                                                 int64_t stride_h, int split, const T* __restrict__ dY2,
+                                                                 int64_t stride_y2, const T* __restrict__ Hm2,
+                                                                 int64_t stride_h2) {
   using frag = typename wfrag<T>::type;
   __shared__ __attribute__((aligned(1024))) T sA0[WBM * WROW], sA1[WBM * WROW], sA2[WBM * WROW], sA3[WBM * WROW];   // dY rows
   __shared__ __attribute__((aligned(1024))) T sB0[WBM * WROW], sB1[WBM * WROW], sB2[WBM * WROW], sB3[WBM * WROW];   // h rows
@@ -86,8 +88,15 @@ __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __res
   const int prob = pslice / slices, slice = pslice - prob * slices;
   const int n0 = (tt / tiles_k) * WBN, k0 = (tt % tiles_k) * WBK;
   const int64_t m_begin = (int64_t)slice * rows_per_slice;
-  dY += (int64_t)prob * stride_y;
-  Hm += (int64_t)prob * stride_h;
+  // products [0, split) lie a constant stride apart from (dY, Hm), products [split, ..) from (dY2, Hm2): two strided groups
+  // of one shape in one launch (the layers' dR and dW: same gradients, two different activation buffers)
+  if (prob < split) {
+    dY += (int64_t)prob * stride_y;
+    Hm += (int64_t)prob * stride_h;
+  } else {
+    dY = dY2 + (int64_t)(prob - split) * stride_y2;
+    Hm = Hm2 + (int64_t)(prob - split) * stride_h2;
+  }
 
   // DMA sources: a stage = 32 rows x 512 B per operand = 16 instructions of 2 rows; wave w brings instructions w and w + 8.
   // Lane l writes the 16-byte piece at (row l >> 5, position l & 31) and fetches the piece that belongs there: granule
@@ -272,31 +281,43 @@ extern "C" double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, i
   return caiman::wgrad_plan(M, N, K, batch, dtype, nullptr, &sec) > 0 ? sec * 1e6 : -1.0;
 }
 
-// `batch` products of one shape: operand p at dY + p * stride_y / H + p * stride_h (elements; rows of N / K elements,
-// contiguous).  slabs [batch][slices][N][K] fp32 (written, not accumulated): slab (p, s) = sum over rows
+// `batch` + `batch2` products of one shape in one launch: product p < batch at dY + p * stride_y / H + p * stride_h, product
+// batch + q at dY2 + q * stride_y2 / H2 + q * stride_h2 (elements; rows of N / K elements, contiguous; batch2 = 0: one
+// group).  slabs [batch + batch2][slices][N][K] fp32 (written, not accumulated): slab (p, s) = sum over rows
 // [s * rows_per_slice, +rows_per_slice) of dY_p[m][n] * H_p[m][k].  Rows from slices * rows_per_slice on are the caller's.
-extern "C" int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch,
-                               int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype,
-                               caiman_stream_t stream) {
+extern "C" int caiman_wgrad_tn2(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, int batch, const void* dY2,
+                                int64_t stride_y2, const void* H2, int64_t stride_h2, int batch2, float* slabs, int64_t M,
+                                int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream) {
   using namespace caiman;
-  CAIMAN_CHECK(caiman_wgrad_tn_plan(M, N, K, batch, dtype, nullptr) > 0, "wgrad_tn: bf16 / f16, N, K %% 256 == 0, M >= 128");
+  CAIMAN_CHECK(batch >= 1 && batch2 >= 0, "wgrad_tn: batch >= 1, batch2 >= 0");
+  CAIMAN_CHECK(caiman_wgrad_tn_plan(M, N, K, batch + batch2, dtype, nullptr) > 0, "wgrad_tn: bf16 / f16, N, K %% 256 == 0, M >= 128");
   CAIMAN_CHECK(slices >= 1 && rows_per_slice >= 96 && rows_per_slice % 32 == 0 && (int64_t)slices * rows_per_slice <= M,
                "wgrad_tn: slices x rows_per_slice must be multiples of 32 rows (>= 96) inside M");
-  CAIMAN_CHECK(dY && H && slabs, "wgrad_tn: null pointer");
+  CAIMAN_CHECK(dY && H && slabs && (batch2 == 0 || (dY2 && H2)), "wgrad_tn: null pointer");
   auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
   CAIMAN_CHECK(al(dY, 16) && al(H, 16) && al(slabs, 16) && stride_y % 8 == 0 && stride_h % 8 == 0 && stride_y >= 0 && stride_h >= 0,
                "wgrad_tn: 16-byte aligned operands and batch strides");
+  CAIMAN_CHECK(batch2 == 0 || (al(dY2, 16) && al(H2, 16) && stride_y2 % 8 == 0 && stride_h2 % 8 == 0 && stride_y2 >= 0 && stride_h2 >= 0),
+               "wgrad_tn: 16-byte aligned operands and batch strides (second group)");
   const int tiles_k = (int)(K / WBK), n_tiles = (int)(N / WBN) * tiles_k;
-  const int64_t grid = (int64_t)n_tiles * slices * batch;
+  const int64_t grid = (int64_t)n_tiles * slices * (batch + batch2);
   CAIMAN_CHECK(grid < ((int64_t)1 << 31), "wgrad_tn: too many tiles");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == CAIMAN_BF16)
     hipLaunchKernelGGL((joint_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const bf16_t*)dY, (const bf16_t*)H,
-                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h);
+                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
+                       (const bf16_t*)dY2, stride_y2, (const bf16_t*)H2, stride_h2);
   else
     hipLaunchKernelGGL((joint_wgrad_kernel<f16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const f16_t*)dY, (const f16_t*)H,
-                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h);
+                       slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
+                       (const f16_t*)dY2, stride_y2, (const f16_t*)H2, stride_h2);
   return check_launch("transposed-read weight gradient");
+}
+extern "C" int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch,
+                               int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype,
+                               caiman_stream_t stream) {
+  return caiman_wgrad_tn2(dY, stride_y, H, stride_h, batch, nullptr, 0, nullptr, 0, 0, slabs, M, N, K, slices, rows_per_slice,
+                          dtype, stream);
 }
 
 // The joint projection's instance (one product): include/caiman_rnnt.h.

@@ -42,6 +42,7 @@ IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # o
 # the layers' weight gradients dG^T . x / dG^T . h_prev on the transposed-read kernel (csrc/joint_wgrad.hip, fp32 results)
 # instead of the library's transposed-A GEMMs; shapes outside its geometry (K = 240 of layer 0) keep the library
 WGRAD_TN = int(__import__("os").environ.get("CAIMAN_LSTM_WGRAD_TN", "1")) != 0
+WGRAD_BOTH = int(__import__("os").environ.get("CAIMAN_LSTM_WGRAD_BOTH", "1")) != 0   # dR and dW of the post layers in one launch
 
 
 def _proj_ok(widths, dt):
@@ -555,9 +556,26 @@ class EncoderPipeFunction(torch.autograd.Function):
         post_R = post_W = post_b = None
         if BMM and Lb > 1:
             dgb = dGb.view(Lb, T2 * B, 4 * H)
-            post_R = tn(dgb, rows3(Yb, 0, Lb, 0, T2))
             xin = rows3(YMb, 0, Lb - 1, 0, T2) if pl[La] > 0.0 else rows3(Yb, 0, Lb - 1, 1, T2)
-            post_W = tn(dgb[1:], xin)
+            both = None
+            if WGRAD_TN and WGRAD_BOTH:
+                # dR of all Lb layers and dW of Lb - 1: one shape, two activation buffers.  As ONE launch when the cost model
+                # prefers that to two (at B = 32: 704 tiles = 2.75 rounds of the chip in one slice, where five layers alone
+                # would leave their last round half empty and go to the library)
+                est = overlap.wgrad_tn_estimate_us
+                rows, e2 = T2 * B, None
+                e_both, e_r, e_w = est(rows, 4 * H, H, 2 * Lb - 1, dt), est(rows, 4 * H, H, Lb, dt), est(rows, 4 * H, H, Lb - 1, dt)
+                lib_us = lambda n: 2.0 * n * rows * 4 * H * H / overlap.LIBRARY_TN_FLOPS * 1e6
+                if e_both > 0:
+                    e2 = min(e_r, lib_us(Lb)) if e_r > 0 else lib_us(Lb)
+                    e2 += min(e_w, lib_us(Lb - 1)) if e_w > 0 else lib_us(Lb - 1)
+                    if e_both < e2:
+                        both = overlap.wgrad_tn(dgb, rows3(Yb, 0, Lb, 0, T2), second=(dgb[1:], xin))
+            if both is not None:
+                post_R, post_W = both[:Lb], both[Lb:]
+            else:
+                post_R = tn(dgb, rows3(Yb, 0, Lb, 0, T2))
+                post_W = tn(dgb[1:], xin)
             post_b = None if fused_db else dgb.sum(1)
         per_layer = [None] * L
         for l in (reversed(range(L)) if direct else range(L)):

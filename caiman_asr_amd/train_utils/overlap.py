@@ -122,40 +122,67 @@ JOINT_WGRAD = __import__("os").environ.get("CAIMAN_JOINT_WGRAD", "1") != "0"
 LIBRARY_TN_FLOPS = 0.8e15   # what the library's transposed-A GEMM reaches at the LSTM layers' shapes (tools/wgrad_tn_bench.py: 0.62-1.03)
 
 
-def wgrad_tn(dy3, x3, only_if_faster=False):
+def _wgrad_group_ok(dy3, x3, P, M, N, K):
+    return (dy3.is_cuda and dy3.dtype in (torch.float16, torch.bfloat16) and x3.dtype == dy3.dtype
+            and tuple(dy3.shape) == (P, M, N) and tuple(x3.shape) == (P, M, K)
+            and dy3.stride(2) == 1 and dy3.stride(1) == N and x3.stride(2) == 1 and x3.stride(1) == K
+            and (P == 1 or (dy3.stride(0) % 8 == 0 and x3.stride(0) % 8 == 0 and dy3.stride(0) >= 0 and x3.stride(0) >= 0))
+            and dy3.data_ptr() % 16 == 0 and x3.data_ptr() % 16 == 0)
+
+
+def wgrad_tn_estimate_us(M, N, K, P, dtype):
+    """what the kernel's cost model expects `P` products [M, N]^T . [M, K] to take in one launch (us; < 0: not supported)"""
+    from caiman_asr_amd import _lib
+
+    return _lib.lib().caiman_wgrad_tn_estimate_us(M, N, K, P, _lib.dtype_tag(dtype))
+
+
+def wgrad_tn(dy3, x3, only_if_faster=False, second=None):
     """dy3 [P, M, N]^T . x3 [P, M, K] per p -> [P, N, K] fp32 through caiman_wgrad_tn (csrc/joint_wgrad.hip: slices of M into
     fp32 slabs, added in order, plus the library product of the few rows the slices do not cover), or None when the shapes or
     strides are outside the kernel (rows must be contiguous, the P operands a constant stride apart) -- or, with
     `only_if_faster`, when the kernel's own cost model expects the library to be quicker (short reductions whose tile
-    count fills the last round of 256 workgroups badly)."""
+    count fills the last round of 256 workgroups badly).  `second` = (dy3b, x3b): a second strided group of products of the
+    SAME shape in the same launch; the result then holds its products behind the first group's."""
     import ctypes
 
     from caiman_asr_amd import _lib
 
     P, M, N = dy3.shape
     K = x3.shape[2]
-    if (not dy3.is_cuda or dy3.dtype not in (torch.float16, torch.bfloat16) or x3.dtype != dy3.dtype or x3.shape[:2] != (P, M)
-            or dy3.stride(2) != 1 or dy3.stride(1) != N or x3.stride(2) != 1 or x3.stride(1) != K):
+    if not _wgrad_group_ok(dy3, x3, P, M, N, K):
         return None
+    P2 = 0
+    if second is not None:
+        dyb, xb = second
+        P2 = dyb.shape[0]
+        if not _wgrad_group_ok(dyb, xb, P2, M, N, K) or dyb.dtype != dy3.dtype:
+            return None
     sy, sx = (dy3.stride(0), x3.stride(0)) if P > 1 else (0, 0)
-    if sy % 8 or sx % 8 or sy < 0 or sx < 0 or dy3.data_ptr() % 16 or x3.data_ptr() % 16:
-        return None
     lib, tag = _lib.lib(), _lib.dtype_tag(dy3.dtype)
+    PT = P + P2
     if only_if_faster:
-        est = lib.caiman_wgrad_tn_estimate_us(M, N, K, P, tag)
-        if est < 0 or est * 1e-6 > 2.0 * P * M * N * K / LIBRARY_TN_FLOPS:
+        est = lib.caiman_wgrad_tn_estimate_us(M, N, K, PT, tag)
+        if est < 0 or est * 1e-6 > 2.0 * PT * M * N * K / LIBRARY_TN_FLOPS:
             return None
     per = ctypes.c_int64(0)
-    slices = lib.caiman_wgrad_tn_plan(M, N, K, P, tag, ctypes.byref(per))
+    slices = lib.caiman_wgrad_tn_plan(M, N, K, PT, tag, ctypes.byref(per))
     if slices <= 0:
         return None
-    slabs = torch.empty((P, slices, N, K), dtype=torch.float32, device=dy3.device)
-    _lib.check(lib.caiman_wgrad_tn(_lib.ptr(dy3), sy, _lib.ptr(x3), sx, _lib.ptr(slabs), P, M, N, K, slices, per.value, tag,
-                                   _lib.stream()))
+    slabs = torch.empty((PT, slices, N, K), dtype=torch.float32, device=dy3.device)
+    if P2:
+        syb, sxb = (dyb.stride(0), xb.stride(0)) if P2 > 1 else (0, 0)
+        _lib.check(lib.caiman_wgrad_tn2(_lib.ptr(dy3), sy, _lib.ptr(x3), sx, P, _lib.ptr(dyb), syb, _lib.ptr(xb), sxb, P2,
+                                        _lib.ptr(slabs), M, N, K, slices, per.value, tag, _lib.stream()))
+    else:
+        _lib.check(lib.caiman_wgrad_tn(_lib.ptr(dy3), sy, _lib.ptr(x3), sx, _lib.ptr(slabs), P, M, N, K, slices, per.value, tag,
+                                       _lib.stream()))
     dw = slabs.sum(1) if slices > 1 else slabs[:, 0]
     done = slices * per.value
     if done < M:
-        dw += torch.bmm(dy3[:, done:].transpose(1, 2), x3[:, done:], out_dtype=torch.float32)
+        dw[:P] += torch.bmm(dy3[:, done:].transpose(1, 2), x3[:, done:], out_dtype=torch.float32)
+        if P2:
+            dw[P:] += torch.bmm(dyb[:, done:].transpose(1, 2), xb[:, done:], out_dtype=torch.float32)
     return dw
 
 

@@ -350,6 +350,12 @@ int caiman_wgrad_tn_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, 
 double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, int batch, int dtype);
 int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch, int64_t M,
                     int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream);
+/* two strided groups of products of one shape in one launch (the layers' dR and dW share the gradients and the shape, not the
+ * activation buffer): products [0, batch) from (dY, H), products [batch, batch + batch2) from (dY2, H2); plan and estimate
+ * with batch + batch2; slabs [batch + batch2][slices][N][K]. */
+int caiman_wgrad_tn2(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, int batch, const void* dY2,
+                     int64_t stride_y2, const void* H2, int64_t stride_h2, int batch2, float* slabs, int64_t M, int64_t N,
+                     int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Transducer joint — replaces apex.contrib.transducer.TransducerJoint (third party, not

@@ -257,3 +257,30 @@ def test_wgrad_tn_declines_what_it_cannot_address():
     assert wgrad_tn(a.transpose(1, 2), a.transpose(1, 2)) is None                                   # rows not contiguous
     assert wgrad_tn(a.float(), a.float()) is None                                                   # fp32 operands
     assert wgrad_tn(a[:, :100], a[:, :100]) is None                                                 # fewer than 128 rows
+
+
+def test_two_strided_groups_in_one_launch():
+    """caiman_wgrad_tn2: the post layers' dR (6 products against [layers, T + 1, B, H] activations from step 0) and dW (5
+    products, the same gradients from layer 1 on against the activations from step 1) as ONE launch of 11 products."""
+    from caiman_asr_amd.train_utils.overlap import wgrad_tn
+
+    L, T, B, H = 6, 35, 8, 256                      # rows = 280 = 8 x 32 + 24: the library takes the last 24 rows
+    g = torch.Generator(device=DEV).manual_seed(17)
+    dG = torch.randn(L, T * B, 4 * H, device=DEV, generator=g).to(torch.bfloat16)
+    Y = torch.randn(L, T + 1, B, H, device=DEV, generator=g).to(torch.bfloat16)
+
+    def rows3(first, count, skip):
+        v = Y[first:first + count, skip:skip + T]
+        return torch.as_strided(v, (count, T * B, H), (Y.stride(0), H, 1), v.storage_offset())
+
+    out = wgrad_tn(dG, rows3(0, L, 0), second=(dG[1:], rows3(0, L - 1, 1)))
+    assert out is not None and out.shape == (2 * L - 1, 4 * H, H)
+    torch.cuda.synchronize()
+    for p in range(2 * L - 1):
+        dy = dG[p] if p < L else dG[p - L + 1]
+        x = Y[p, :T] if p < L else Y[p - L, 1:T + 1]
+        ref = dy.double().t() @ x.reshape(T * B, H).double()
+        err = (out[p].double() - ref).abs().max().item()
+        assert err <= 2e-5 * ref.abs().max().item(), (p, err)
+    # a second group of another shape is declined, not mis-read
+    assert wgrad_tn(dG, rows3(0, L, 0), second=(dG[1:, :128], rows3(0, L - 1, 1)[:, :128])) is None
