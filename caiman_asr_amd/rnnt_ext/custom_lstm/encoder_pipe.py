@@ -577,6 +577,20 @@ class EncoderPipeFunction(torch.autograd.Function):
                 post_R = tn(dgb, rows3(Yb, 0, Lb, 0, T2))
                 post_W = tn(dgb[1:], xin)
             post_b = None if fused_db else dgb.sum(1)
+        # pre layers: dR of all La layers and dW of layers 1 .. La - 1 have one shape (layer 0's dW has K = in_feats): one
+        # launch of the weight-gradient kernel where its cost model prefers that to one product at a time
+        pre_R = pre_W = None
+        if WGRAD_TN and WGRAD_BOTH and La >= 2 and all(Hl[l] == H for l in range(La)):
+            est = overlap.wgrad_tn_estimate_us
+            rows = T1 * B
+            e_all, e_one = est(rows, 4 * H, H, 2 * La - 1, dt), est(rows, 4 * H, H, 1, dt)
+            lib_one = 2.0 * rows * 4 * H * H / overlap.LIBRARY_TN_FLOPS * 1e6
+            if e_all > 0 and e_all < (2 * La - 1) * (min(e_one, lib_one) if e_one > 0 else lib_one):
+                dga = dGa.view(La, T1 * B, 4 * H)
+                xin_a = rows3(YMa, 0, La - 1, 0, T1) if pl[0] > 0.0 else rows3(Ya, 0, La - 1, 1, T1)
+                got = overlap.wgrad_tn(dga, rows3(Ya, 0, La, 0, T1), second=(dga[1:], xin_a))
+                if got is not None:
+                    pre_R, pre_W = got[:La], got[La:]
         per_layer = [None] * L
         for l in (reversed(range(L)) if direct else range(L)):
             T, hl = Tl[l], Hl[l]
@@ -586,6 +600,10 @@ class EncoderPipeFunction(torch.autograd.Function):
                 dB = dbias[l, :4 * hl] if fused_db else post_b[m]
                 gW = post_W[m - 1] if m >= 1 else tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0]
                 g4 = [gW, post_R[m], dB, dB]
+            elif pre_R is not None and l < La:
+                dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)
+                gW = pre_W[l - 1] if l >= 1 else tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0]
+                g4 = [gW, pre_R[l], dB, dB]
             else:
                 yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
                 dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)

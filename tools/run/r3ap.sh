@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r3ap
 mkdir -p $O
 cd $R
-timeout -k 10 900 python3 -m pytest tests/test_gpu_joint_gemm.py tests/test_gpu_train_step.py tests/test_gpu_fullsize.py -x -q > $O/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $O/tests.log
+timeout -k 10 900 python3 -m pytest tests/test_gpu_lstm.py tests/test_gpu_train_step.py tests/test_gpu_fullsize.py tests/test_gpu_model.py -x -q > $O/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $O/tests.log
 [ $rc -eq 0 ] || exit $rc
 for v in 1 0 1 0 1 0; do
   CAIMAN_LSTM_WGRAD_BOTH=$v timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-kernel-timing > $O/base_both${v}_$RANDOM.json 2> $O/base.err; echo "both=$v rc=$?"
