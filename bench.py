@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--main-priority", type=int, default=0,
                     help="run the step on a stream of this priority (-1 = above the side streams; 0 = the default stream; measured: no effect)")
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
+    ap.add_argument("--sequential-augment", action="store_true",
+                    help="SpecAugment, FrameSplicing and PermuteAudio as separate torch modules instead of the fused kernel (A/B)")
     ap.add_argument("--feed", action="store_true",
                     help="after the timed loop, time the same steps again WHILE the data feed (AudioBatchLoader: 8 FLAC decode "
                          "threads, side-stream log-mel / normalise / splice kernels) produces one batch per step (N = 1 only)")
@@ -326,7 +328,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from caiman_asr_amd import _lib
-    from caiman_asr_amd.data.features import FrameSplicing, SpecAugment
+    from caiman_asr_amd.data.features import FrameSplicing, SpecAugment, augment_splice_permute
     from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers, get_packing_meta_data
     from caiman_asr_amd.rnnt.model import RNNT
     from caiman_asr_amd.train_utils.distributed import FlatGradReducer, broadcast_parameters
@@ -372,9 +374,12 @@ def main():
         feats, feat_lens_h, txt, txt_lens_h = dev_batches[i % n_distinct]
         lr_policy(optimizer, initial_lrs, 4e-4, global_step, 1632, 18000, 10880)
         feat_lens_d = feat_lens_h.to(dev, non_blocking=True)
-        x, _ = spec((feats, feat_lens_d))
-        x, lens_h = splice((x, feat_lens_h))           # lens on the host: no device sync
-        x = x.permute(2, 0, 1).contiguous()            # PermuteAudio: [T1, B, 240]
+        if args.sequential_augment:                        # the three feature processors one at a time (A/B)
+            x, _ = spec((feats, feat_lens_d))
+            x, lens_h = splice((x, feat_lens_h))
+            x = x.permute(2, 0, 1).contiguous()
+        else:   # SpecAugment masks + frame splicing + PermuteAudio as one kernel (lens on the host: no device sync): [T1, B, 240]
+            x, lens_h = augment_splice_permute(spec, splice, feats, feat_lens_d, feat_lens_h)
         meta = get_packing_meta_data(lens_h, txt_lens_h, 2, device=dev)
         lens_d = lens_h.to(dev, non_blocking=True)
         txt_lens_d = txt_lens_h.to(dev, non_blocking=True)

@@ -176,6 +176,7 @@ _SIGS = {
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),
+    "caiman_specaug_splice": ([P, I64, I64, I64, P, P, I32, P, P, I32, I32, I32, I64, P, P], ctypes.c_int),
     "caiman_joint_forward": ([P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, F64, ctypes.c_uint64, I32, P, P],
                              ctypes.c_int),
     "caiman_joint_backward": ([P, P, P, P, P, I64, I64, I64, I64, I32, I32, F64, I32, P, P, P], ctypes.c_int),

@@ -158,6 +158,67 @@ __global__ __launch_bounds__(256) void mel_normalize_kernel(float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// SpecAugment masks applied + frame splicing + PermuteAudio in one pass:
+//   out[t1][b][n * F + f] = masked(x[b][f][t1 * subsampling + n])      n < stacking, zero past T
+// where `masked` zeroes frequency rows inside any [f0, f0 + fw) and frames inside any [t0, t0 + tw) of utterance b
+// (training/caiman_asr_train/data/features.py:34-115 `SpecAugment`, :118-139 `stack_subsample_frames`, :160-162
+// `PermuteAudio`).  As torch ops this was masked_fill + two cats + a strided slice + a permuted copy (five passes over up to
+// 51 MB) behind a dozen small launches that built the boolean mask; the mask GEOMETRY (a few numbers per utterance) stays
+// where it was drawn.  A workgroup takes 32 output frames of one utterance: reads the (32 - 1) * subsampling + stacking input
+// frames of all F rows along t (coalesced) into LDS, writes 32 rows of F * stacking values (coalesced).
+// ---------------------------------------------------------------------------
+constexpr int kSpliceFrames = 32;
+__global__ __launch_bounds__(256) void specaug_splice_kernel(const float* __restrict__ x, int64_t F, int64_t T,
+                                                             const float* __restrict__ f0, const float* __restrict__ fw, int nf,
+                                                             const float* __restrict__ t0, const float* __restrict__ tw, int nt,
+                                                             int stacking, int subsampling, int64_t T_out, int64_t B,
+                                                             float* __restrict__ out) {
+  extern __shared__ float sm[];
+  const int span = (kSpliceFrames - 1) * subsampling + stacking;
+  const int pitch = span | 1;                       // odd: the F-strided reads of the store phase hit distinct banks
+  float* tile = sm;                                 // [F][pitch]
+  unsigned char* fmask = reinterpret_cast<unsigned char*>(sm + F * pitch);   // [F]
+  unsigned char* tmask = fmask + F;                                           // [span]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int64_t t1_0 = (int64_t)blockIdx.x * kSpliceFrames, tb = t1_0 * subsampling;
+  for (int f = tid; f < F; f += blockDim.x) {
+    bool m = false;
+    for (int i = 0; i < nf; ++i) {
+      const float a = f0[(int64_t)b * nf + i];
+      m |= (float)f >= a && (float)f < a + fw[(int64_t)b * nf + i];
+    }
+    fmask[f] = m;
+  }
+  for (int d = tid; d < span; d += blockDim.x) {
+    const float t = (float)(tb + d);
+    bool m = false;
+    for (int i = 0; i < nt; ++i) {
+      const float a = t0[(int64_t)b * nt + i];
+      m |= t >= a && t < a + tw[(int64_t)b * nt + i];
+    }
+    tmask[d] = m;
+  }
+  __syncthreads();
+  const float* xb = x + (int64_t)b * F * T;
+  for (int idx = tid; idx < F * span; idx += blockDim.x) {
+    const int f = idx / span, d = idx - f * span;
+    const int64_t t = tb + d;
+    float v = t < T ? xb[(int64_t)f * T + t] : 0.f;
+    if (fmask[f] | tmask[d]) v = 0.f;
+    tile[f * pitch + d] = v;
+  }
+  __syncthreads();
+  const int C = (int)F * stacking;
+  for (int idx = tid; idx < kSpliceFrames * C; idx += blockDim.x) {
+    const int tt = idx / C, c = idx - tt * C;
+    const int n = c / (int)F, f = c - n * (int)F;
+    const int64_t t1 = t1_0 + tt;
+    if (t1 < T_out) out[(t1 * B + b) * C + c] = tile[f * pitch + tt * subsampling + n];
+  }
+}
+
 }  // namespace
 }  // namespace caiman
 
@@ -195,4 +256,22 @@ extern "C" int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int
   hipLaunchKernelGGL(mel_normalize_kernel, dim3((unsigned)nmel, (unsigned)B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, len, T, nmel, ds_mean, ds_std, ratio);
   return check_launch("caiman_mel_normalize");
+}
+
+extern "C" int caiman_specaug_splice(const float* x, int64_t B, int64_t F, int64_t T, const float* f0, const float* fw, int nf,
+                                     const float* t0, const float* tw, int nt, int stacking, int subsampling, int64_t T_out,
+                                     float* out, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(B >= 1 && B <= 65535 && F >= 1 && F <= 1024 && T >= 1, "specaug_splice: bad extents");
+  CAIMAN_CHECK(stacking >= 1 && stacking <= 16 && subsampling >= 1 && subsampling <= 16, "specaug_splice: stacking / subsampling in [1, 16]");
+  CAIMAN_CHECK(T_out >= 1 && T_out <= (T + subsampling - 1) / subsampling, "specaug_splice: T_out must be in [1, ceil(T / subsampling)]");
+  CAIMAN_CHECK(nf >= 0 && nt >= 0 && (nf == 0 || (f0 && fw)) && (nt == 0 || (t0 && tw)), "specaug_splice: mask arrays");
+  CAIMAN_CHECK(x && out, "specaug_splice: null pointer");
+  const int span = (kSpliceFrames - 1) * subsampling + stacking, pitch = span | 1;
+  const size_t lds = (size_t)F * pitch * sizeof(float) + (size_t)F + (size_t)span + 8;
+  CAIMAN_CHECK(lds <= 64 * 1024, "specaug_splice: %lld feature rows x %d frames do not fit the tile", (long long)F, span);
+  const dim3 grid((unsigned)((T_out + kSpliceFrames - 1) / kSpliceFrames), (unsigned)B);
+  hipLaunchKernelGGL(specaug_splice_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, F, T, f0, fw, nf, t0, tw,
+                     nt, stacking, subsampling, T_out, B, out);
+  return check_launch("caiman_specaug_splice");
 }

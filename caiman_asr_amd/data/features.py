@@ -33,20 +33,19 @@ class SpecAugment(BaseFeatures):
         self.noise_magnitude = noise_magnitude
 
     @torch.no_grad()
-    def make_mask(self, shape, x_lens, device, generator=None):
+    def mask_geometry(self, shape, x_lens, device, generator=None):
+        """-> (f0, fw, t0, tw): start and width of every frequency mask [B, freq_masks] and time mask [B, max_n] (float
+        tensors holding integers; width 0 = no mask; None where there are no masks of that kind).  All drawn on the device."""
         B, F, T = shape
         lens = x_lens.to(device=device, dtype=torch.float32)
-        mask = torch.zeros((B, F, T), dtype=torch.bool, device=device)
 
         def rnd(*size):
             return torch.rand(*size, device=device, generator=generator)
 
+        f0 = fw = t0 = tw = None
         if self.freq_masks > 0:
-            w = torch.floor(rnd(B, self.freq_masks) * (self.max_freq - self.min_freq + 1)) + self.min_freq
-            f0 = torch.floor(rnd(B, self.freq_masks) * torch.clamp(F - w + 1, min=1))
-            idx = torch.arange(F, device=device).view(1, 1, F)
-            fm = ((idx >= f0.unsqueeze(-1)) & (idx < (f0 + w).unsqueeze(-1))).any(1)
-            mask |= fm.unsqueeze(-1)
+            fw = torch.floor(rnd(B, self.freq_masks) * (self.max_freq - self.min_freq + 1)) + self.min_freq
+            f0 = torch.floor(rnd(B, self.freq_masks) * torch.clamp(F - fw + 1, min=1))
         # adaptive count / width per utterance
         if 0 < self.time_masks < 1.0:
             n_masks = torch.round(lens * self.time_masks)
@@ -62,9 +61,21 @@ class SpecAugment(BaseFeatures):
             w = torch.floor(rnd(B, max_n) * (max_t.unsqueeze(1) - self.min_time + 1)) + self.min_time
             t0 = torch.floor(rnd(B, max_n) * torch.clamp(T - w + 1, min=1))
             live = torch.arange(max_n, device=device).view(1, max_n) < n_masks.view(B, 1)
-            w = torch.where(live, w, torch.zeros_like(w))
+            tw = torch.where(live, w, torch.zeros_like(w))
+        return f0, fw, t0, tw
+
+    @torch.no_grad()
+    def make_mask(self, shape, x_lens, device, generator=None):
+        B, F, T = shape
+        f0, fw, t0, tw = self.mask_geometry(shape, x_lens, device, generator)
+        mask = torch.zeros((B, F, T), dtype=torch.bool, device=device)
+        if f0 is not None:
+            idx = torch.arange(F, device=device).view(1, 1, F)
+            fm = ((idx >= f0.unsqueeze(-1)) & (idx < (f0 + fw).unsqueeze(-1))).any(1)
+            mask |= fm.unsqueeze(-1)
+        if t0 is not None:
             idx = torch.arange(T, device=device).view(1, 1, T)
-            tm = ((idx >= t0.unsqueeze(-1)) & (idx < (t0 + w).unsqueeze(-1))).any(1)
+            tm = ((idx >= t0.unsqueeze(-1)) & (idx < (t0 + tw).unsqueeze(-1))).any(1)
             mask |= tm.unsqueeze(1)
         return mask
 
@@ -106,3 +117,37 @@ class FrameSplicing(BaseFeatures):
 class PermuteAudio(nn.Module):
     def forward(self, x):
         return (x[0].permute(2, 0, 1), *x[1:])
+
+
+@torch.no_grad()
+def augment_splice_permute(spec, splice, feats, feat_lens, feat_lens_host, generator=None):
+    """`PermuteAudio(FrameSplicing(SpecAugment(feats)))` in one kernel (include/caiman_rnnt.h caiman_specaug_splice): feats
+    [B, F, T] f32 on the GPU -> (x [T_out, B, F * stacking] contiguous, lens on the host).  The masks are the ones
+    `spec.make_mask` would build from the same generator state (`mask_geometry` draws them; the kernel applies them while it
+    stacks, subsamples and transposes).  `spec` may be None (no augmentation: evaluation).  The separate modules stay for
+    callers that want them one at a time, and are what the tests compare this with."""
+    from caiman_asr_amd import _lib
+
+    assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 3
+    feats = feats.contiguous()
+    B, F, T = feats.shape
+    st, sub = splice.frame_stacking, splice.frame_subsampling
+    lens_out = torch.ceil(feat_lens_host.float() / sub).int() if sub > 1 else feat_lens_host
+    t_all = (T + sub - 1) // sub
+    t_out = t_all
+    if sub > 1:
+        max_len = int(lens_out.max().item())
+        if t_all > max_len:
+            assert t_all - max_len <= 1
+            t_out = max_len
+    f0 = fw = t0 = tw = None
+    if spec is not None:
+        f0, fw, t0, tw = spec.mask_geometry(feats.shape, feat_lens, feats.device, generator)
+    cf = lambda t: None if t is None else t.float().contiguous()
+    f0, fw, t0, tw = cf(f0), cf(fw), cf(t0), cf(tw)
+    out = torch.empty((t_out, B, F * st), dtype=torch.float32, device=feats.device)
+    _lib.check(_lib.lib().caiman_specaug_splice(
+        _lib.ptr(feats), B, F, T, _lib.ptr(f0) if f0 is not None else None, _lib.ptr(fw) if fw is not None else None,
+        0 if f0 is None else f0.shape[1], _lib.ptr(t0) if t0 is not None else None, _lib.ptr(tw) if tw is not None else None,
+        0 if t0 is None else t0.shape[1], st, sub, t_out, _lib.ptr(out), _lib.stream()))
+    return out, lens_out

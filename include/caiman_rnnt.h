@@ -440,6 +440,15 @@ int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int nmel, int6
                          const float* ds_mean, const float* ds_std, float ratio,
                          caiman_stream_t stream);
 
+/* SpecAugment masks applied + frame splicing + PermuteAudio in one pass — replaces the tail of the reference's feature
+ * processors (training/caiman_asr_train/data/features.py:34-115 `SpecAugment.calculate_features`' masked_fill, :118-139
+ * `stack_subsample_frames`, :160-162 `PermuteAudio`): x [B, F, T] f32;  f0 / fw [B, nf], t0 / tw [B, nt]: start and width
+ * of every frequency / time mask of utterance b (width 0: no mask; the caller draws them);  out [T_out, B, F * stacking] f32
+ * with out[t1][b][n * F + f] = masked x[b][f][t1 * subsampling + n], zero past T;  T_out <= ceil(T / subsampling). */
+int caiman_specaug_splice(const float* x, int64_t B, int64_t F, int64_t T, const float* f0, const float* fw, int nf,
+                          const float* t0, const float* tw, int nt, int stacking, int subsampling, int64_t T_out,
+                          float* out, caiman_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,3 +65,39 @@ def test_spec_augment_issues_no_host_sync():
         spec((x, lens))
     finally:
         torch.cuda.set_sync_debug_mode("default")
+
+
+@pytest.mark.parametrize("B,F,T,stack,sub,with_spec", [
+    (5, 80, 903, 3, 3, True),      # the training configuration: 80 mels, stack 3 / subsample 3, T not a multiple of 3
+    (3, 80, 64, 3, 3, True),       # two tiles of 32 output frames at most; the trim to ceil(max len / 3)
+    (4, 80, 1670, 3, 3, False),    # no augmentation (evaluation)
+    (2, 64, 257, 2, 1, True),      # stacking without subsampling
+    (2, 40, 100, 1, 2, True),      # subsampling without stacking
+])
+def test_fused_augment_splice_permute_equals_the_three_modules(B, F, T, stack, sub, with_spec):
+    """caiman_specaug_splice (one kernel) against PermuteAudio(FrameSplicing(SpecAugment(x))) as separate torch modules on
+    the same random state: the same tensor, bit for bit (the kernel only moves and zeroes values), and the same lengths."""
+    from caiman_asr_amd.data.features import FrameSplicing, SpecAugment, augment_splice_permute
+
+    torch.manual_seed(T + B)
+    lens_h = torch.randint(max(T // 2, 1), T + 1, (B,), dtype=torch.int32)
+    lens_h[0] = T
+    if B > 1 and T > 40:
+        lens_h[1] = T - 2          # max length decides the trim
+    x = torch.randn(B, F, T, device=DEV)
+    spec = SpecAugment(freq_masks=2, min_freq=0, max_freq=20, time_masks=0.04, min_time=0, max_time=0.03) if with_spec else None
+    splice = FrameSplicing(frame_stacking=stack, frame_subsampling=sub)
+    torch.manual_seed(99)
+    y = x.clone()
+    if spec is not None:
+        y, _ = spec((y, lens_h.to(DEV)))
+    y, lens_ref = splice((y, lens_h))
+    ref = y.permute(2, 0, 1).contiguous()
+    torch.manual_seed(99)
+    got, lens_got = augment_splice_permute(spec, splice, x, lens_h.to(DEV), lens_h)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and got.is_contiguous()
+    assert torch.equal(got, ref)
+    assert torch.equal(lens_got.cpu(), lens_ref.cpu())
+    if with_spec:
+        assert (got == 0).float().mean() > 0.01      # masks were applied
