@@ -22,7 +22,8 @@ from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
 from caiman_asr_amd.rnnt_ext.custom_lstm import stack
 from caiman_asr_amd.rnnt_ext.custom_lstm.stack import INTERLEAVED, RINGS_ZEROED, _pad32, _perm_rows, _Scratch, _unperm_rows
 
-CH = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_CHUNK", "32"))   # timesteps per pipeline chunk
+# timesteps per pipeline chunk: 0 = by hidden size (`_chunk`); CAIMAN_ENC_PIPE_CHUNK forces a value
+CH = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_CHUNK", "0"))
 # post_rnn chunks of CH / factor steps: a post chunk then needs exactly one pre chunk, every post layer works in every
 # tick (for CH / factor launches) and the pipeline drains in half the launches; costs smaller input GEMMs
 FINE = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_FINE", "1")) != 0
@@ -104,17 +105,26 @@ def eligible(x, hidden, La, Lb, gate_dtype, factor):
             and gate_dtype in (torch.float16, torch.bfloat16))
 
 
-def _post_chunk(f):
-    return CH // f if (FINE and CH % f == 0 and CH // f >= 4) else CH
+def _chunk(H):
+    """Timesteps per pipeline chunk.  Measured on the final round-3 tree (bench.py, two runs each): H = 1024 (base-85M) 24:
+    26.26-26.39 ms, 28: 26.6, 32: 26.5-26.6, 40: 26.7, 48: 26.8, 64: 27.4 (B = 128: 90.1 vs 91.1 at 32); 16 and 20 lose the
+    half-length post chunks' alignment and triple the host time.  H = 1536 (large-196M, two launches per tick): 32: 55.7, 24:
+    56.3.  Shorter chunks fill and drain the layer pipeline faster; what they cost is one projection + one resident launch
+    more per 8 timesteps, which the round-3 projection kernels made cheaper."""
+    return CH if CH > 0 else (24 if H <= 1024 else 32)
 
 
-def _schedule(nA, nB, La, Lb, f, nP=0, Lp=0):
+def _post_chunk(f, ch):
+    return ch // f if (FINE and ch % f == 0 and ch // f >= 4) else ch
+
+
+def _schedule(nA, nB, La, Lb, f, nP=0, Lp=0, ch=32):
     """-> list of ticks, each a list of (layer, chunk).  Layers: pre 0..La-1, post La..La+Lb-1, prediction after."""
     ticks = {}
     for l in range(La):
         for k in range(nA):
             ticks.setdefault(k + l, []).append((l, k))
-    per = 1 if _post_chunk(f) != CH else f                # pre chunks stacked into one post chunk
+    per = 1 if _post_chunk(f, ch) != ch else f            # pre chunks stacked into one post chunk
     for m in range(Lb):
         for j in range(nB):
             ready = min(per * j + per - 1, nA - 1) + La   # the last pre chunk it stacks is done at the end of tick (c + La - 1)
@@ -256,13 +266,14 @@ class EncoderPipeFunction(torch.autograd.Function):
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), _lib.ptr(Y[l][0]), _lib.ptr(wt[l]),
                                                 _lib.ptr(ring[l]), None, B, Hl[l], tag, 0, INTERLEAVED | RINGS_ZEROED, st))
-        CHb = _post_chunk(f)
+        CH = _chunk(H)
+        CHb = _post_chunk(f, CH)
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), False) if h else 0 for h in Hl]
         Wt_post = torch.stack([Wp[l] for l in range(La + 1, Le)]) if (BMM and Lb > 2 and not use_proj) else None      # [Lb-1, H, 4H]
         b_post = torch.stack([bias[l] for l in range(La + 1, Le)]).unsqueeze(1) if Wt_post is not None else None
-        sched = _schedule(nA, nB, La, Lb, f, nP, Lp)
+        sched = _schedule(nA, nB, La, Lb, f, nP, Lp, CH)
         if use_proj:
             gp = [g_.data_ptr() for g_ in G]
             # input rows of layer l: the (masked) output of the layer below, one row block [B, H] per timestep
@@ -414,7 +425,8 @@ class EncoderPipeFunction(torch.autograd.Function):
         for l in range(L):
             _lib.check(lib.caiman_lstm_prepare(None if flags[3] else _lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
                                                 _lib.ptr(dC[l]), B, Hl[l], tag, 1, INTERLEAVED | RINGS_ZEROED, st))
-        CHb = _post_chunk(f)
+        CH = _chunk(H)
+        CHb = _post_chunk(f, CH)
         CHl = [CH] * La + [CHb] * Lb + [CH] * Lp
         nA, nB, nP = (T1 + CH - 1) // CH, (T2 + CHb - 1) // CHb, (Tp + CH - 1) // CH
         sbytes = [_step_bytes(B, h, Ga.element_size(), True) if h else 0 for h in Hl]
@@ -426,7 +438,7 @@ class EncoderPipeFunction(torch.autograd.Function):
         boundary_done = set()   # post chunks whose input gradient has been un-stacked into delta[La-1]
         use_proj = _proj_ok(set(Hl) | {f * H}, dt)
         W_post = torch.stack([Wp[l] for l in range(La + 1, Le)]).transpose(1, 2) if (BMM and Lb > 2 and not use_proj) else None   # views [Lb-1, 4H, H]
-        sched = list(reversed(_schedule(nA, nB, La, Lb, f, nP, Lp)))
+        sched = list(reversed(_schedule(nA, nB, La, Lb, f, nP, Lp, CH)))
         if use_proj:
             # input gradients of a tick's chunks: delta_l = dG_{l+1} @ W_{l+1} (W stored [K_in, 4H] = the kernel's [N][K]
             # operand), the top pre layer's through StackTime (the columns of a row scatter to f frames)

@@ -163,15 +163,16 @@ def test_encoder_pipeline_schedule_respects_dependencies():
     import importlib
 
     ep = importlib.import_module("caiman_asr_amd.rnnt_ext.custom_lstm.encoder_pipe")
-    CH = ep.CH
+    assert ep._chunk(1024) in (24, ep.CH) and ep._chunk(1536) in (32, ep.CH)
     for fine in (True, False):
+      for CH in (24, 32):
         ep.FINE = fine
         for T1, La, Lb, f, Tp, Lp in [(430, 2, 6, 2, 0, 0), (75, 2, 3, 2, 0, 0), (33, 1, 1, 2, 0, 0), (70, 2, 3, 3, 0, 0),
                                       (557, 2, 6, 2, 0, 0), (430, 2, 4, 2, 58, 2), (1, 2, 6, 2, 1, 2), (64, 3, 5, 1, 0, 0)]:
             T2 = -(-T1 // f)
-            CHb = ep._post_chunk(f)
+            CHb = ep._post_chunk(f, CH)
             nA, nB, nP = -(-T1 // CH), -(-T2 // CHb), -(-Tp // CH) if Lp else 0
-            ticks = ep._schedule(nA, nB, La, Lb, f, nP, Lp)
+            ticks = ep._schedule(nA, nB, La, Lb, f, nP, Lp, CH)
             when = {}
             for t, tick in enumerate(ticks):
                 assert 1 <= len(tick) <= 8
