@@ -438,6 +438,13 @@ def main():
         log(f"warm-up step {i} done")
         if i == 0:
             loss_fn.t_loss.validate_lengths = False  # inputs validated once; no per-step host syncs
+    # A full (generation-2) pass of Python's cycle collector over everything the set-up has allocated takes ~100 ms on this
+    # host, and its trigger is a count of allocations: it fell on whichever step reached the count (step 14 of a run at 32
+    # timesteps per chunk, step 10 at 24 -- inside or outside the 12 timed steps by accident).  What exists now is long-lived:
+    # move it out of the collector's reach, as a training loop does once its model and loaders are built.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     if reducer is not None:
         reducer.exposed_ms()   # drop the warm-up steps' events
