@@ -33,6 +33,8 @@
 // contiguous run of tiles, M-tile major, so the 34 workgroups that share an activation panel share an L2.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
+#include <type_traits>
 
 #include "common.h"
 
@@ -234,6 +236,273 @@ __global__ __launch_bounds__(64 * JNW, 1) void joint_fc_gemm_kernel(const T* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same product on an 8-PHASE main loop with the two waves of every SIMD in OPPOSITE roles.
+//
+// The ring kernel above runs all eight waves in lockstep: everyone waits, everyone reads 12 fragments, everyone issues 32
+// MFMAs -- the matrix pipe idles while both waves of a SIMD read, and the LDS idles while both multiply (43.7 % MFMA busy
+// under the profiler).  Here a K tile of 64 is cut into FOUR phases of 16 MFMAs per wave (one 64 x 32 quadrant of the wave's
+// 128 x 64 tile over the whole K tile), every phase is  [ds_read fragments | issue one LDS-DMA unit | counted vmcnt]
+// s_barrier  [lgkmcnt(0) | 16 MFMA]  s_barrier, and waves 4-7 run ONE BARRIER BEHIND waves 0-3: while one wave of a SIMD
+// multiplies, its partner reads and issues, then they swap.  The matrix pipe sees 16 MFMAs from one wave, then 16 from the
+// other, back to back.
+//
+// Staging units (16 KB each = 128 rows x 64 K values; two K tiles of four units = 128 KB of LDS, eight separate LDS objects
+// named statically so that the compiler can tell the unit a ds_read touches from the units in flight):
+//   type 0  A rows {wr * 128 + 0 .. 63}   (the first 64 rows of BOTH wave-row halves: what phase 0 multiplies)
+//   type 1  W rows {wc * 64 + 0 .. 31}    (phase 0 and, from registers, phase 3)
+//   type 2  W rows {wc * 64 + 32 .. 63}   (phases 1, 2)
+//   type 3  A rows {wr * 128 + 64 .. 127} (phases 2, 3)
+// Unit u = 4 * tile + type is issued at phase u - 6 by all eight waves (two 1 KB LDS-DMA instructions each), every phase ends
+// its load part with vmcnt(8) -- the four youngest units may still fly, unit <= phase + 2 has landed -- and unit u is first
+// read at phase u - 1 or u: one phase AFTER the wait that retires it, as the guide's placement rule demands for waves
+// staggered by a barrier.  Unit u + 8 overwrites unit u at phase u + 2, two phases after the last read of u (type 0 is read
+// at phase u).  Rows are 128 B; 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) (swizzle applied to the DMA's
+// SOURCE address and to the read address): the four 16-lane groups of a ds_read_b128 each hit 16 distinct bank groups.
+template <typename T, bool LSE, bool BIAS>
+__global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                                const T* __restrict__ bias, T* __restrict__ C,
+                                                                float* __restrict__ pmax, float* __restrict__ psum, int M,
+                                                                int N, int K, int tiles_n, int tiles_m, int group) {
+  using frag = typename jfrag<T>::type;
+  constexpr int UE = 128 * 64;   // elements of a unit
+  __shared__ __attribute__((aligned(1024))) T u00[UE], u01[UE], u02[UE], u03[UE], u10[UE], u11[UE], u12[UE], u13[UE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+  int t;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  {
+    const int per = group * tiles_n, g = t / per, w_ = t - g * per;
+    const int gm = min(group, tiles_m - g * group);
+    tn = w_ / gm;
+    tm = g * group + (w_ - tn * gm);
+  }
+  const int m0 = tm * JBM, n0 = tn * JBN;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // DMA sources: per unit type two instructions per wave; instruction i of wave w fills unit rows (2 w + i) * 8 .. + 7,
+  // lane l the chunk at (row l >> 3, position l & 7)
+  unsigned src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rho = (wave * 2 + i) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((rho >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ra = (rho >> 6) * 128 + h * 64 + (rho & 63);
+      if (m0 + ra >= M) ra = M - 1 - m0;                       // rows past M re-read the last row; never stored
+      const int rw = (rho >> 5) * 64 + h * 32 + (rho & 31);
+      src[h ? 3 : 0][i] = (unsigned)((ra * K + ch * 8) * (int)sizeof(T));
+      src[h ? 2 : 1][i] = (unsigned)((rw * K + ch * 8) * (int)sizeof(T));
+    }
+  }
+  const char* a_base = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
+  const char* w_base = reinterpret_cast<const char*>(W + (int64_t)n0 * K);
+
+#define CAIMAN_UNIT(PAR, TY) \
+  ((PAR) == 0 ? ((TY) == 0 ? u00 : (TY) == 1 ? u01 : (TY) == 2 ? u02 : u03) : ((TY) == 0 ? u10 : (TY) == 1 ? u11 : (TY) == 2 ? u12 : u13))
+
+  // ga / gw: wave-uniform pointers to column (first K tile of the pair being multiplied) of the tile's first A / W row
+  const char* ga = a_base;
+  const char* gw = w_base;
+  auto issue = [&](auto PAR_, auto TY_, auto AHEAD_) {
+    constexpr int PAR = decltype(PAR_)::value, TY = decltype(TY_)::value, AHEAD = decltype(AHEAD_)::value;
+    T* dst = CAIMAN_UNIT(PAR, TY);
+    // (the instruction's immediate offset is no place for the K advance: the hardware adds it to the LDS address as well)
+    const char* gb = ((TY == 0 || TY == 3) ? ga : gw) + AHEAD * 64 * (int)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + src[TY][i]),
+                                       (__attribute__((address_space(3))) void*)(dst + (wave * 2 + i) * 8 * 64), 16, 0, 0);
+  };
+
+  // fragment read offsets inside a unit (elements): k-step 0 and 1 differ by an XOR on the chunk, hence two bases per operand
+  const int swz = (r16 >> 1) & 7;
+  int abase[2], wbase[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    abase[ks] = (wr * 64 + r16) * 64 + (((ks * 4 + kq) ^ swz) * 8);
+    wbase[ks] = (wc * 32 + r16) * 64 + (((ks * 4 + kq) ^ swz) * 8);
+  }
+
+  // accumulators [mh][b][nh][a]: rows m0 + wr * 128 + mh * 64 + b * 16 + r16, columns n0 + wc * 64 + nh * 32 + a * 16 + kq * 4 + j.
+  // They start at the bias (the lane's four columns), so the epilogue has no bias pass.  The four bias loads are the oldest
+  // vector-memory operations of the wave: the first counted wait retires them with the first units.
+  using v4 = __attribute__((ext_vector_type(4))) T;
+  f32x4 acc[2][4][2][2];
+  v4 braw[4];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) braw[c] = *reinterpret_cast<const v4*>(bias + n0 + wc * 64 + c * 16 + kq * 4);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  frag af[4][2], wf[2][2][2];
+  // one phase.  PAR: parity of the K tile being multiplied; PH: phase 0..3; ISSUE: stage unit (phase + 6) of K tile kt;
+  // VM: the counted wait behind it (-1: none)
+  auto phase = [&](auto PAR_, auto PH_, auto ISSUE_, auto VM_) {
+    constexpr int PAR = decltype(PAR_)::value, PH = decltype(PH_)::value, VM = decltype(VM_)::value;
+    constexpr bool ISSUE = decltype(ISSUE_)::value != 0;
+    // ---- load part
+    if constexpr (PH == 0) {
+      const T* ua = CAIMAN_UNIT(PAR, 0);
+      const T* uw = CAIMAN_UNIT(PAR, 1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[0][a][ks] = *reinterpret_cast<const frag*>(uw + wbase[ks] + a * 16 * 64);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[b][ks] = *reinterpret_cast<const frag*>(ua + abase[ks] + b * 16 * 64);
+    } else if constexpr (PH == 1) {
+      const T* uw = CAIMAN_UNIT(PAR, 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[1][a][ks] = *reinterpret_cast<const frag*>(uw + wbase[ks] + a * 16 * 64);
+    } else if constexpr (PH == 2) {
+      const T* ua = CAIMAN_UNIT(PAR, 3);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[b][ks] = *reinterpret_cast<const frag*>(ua + abase[ks] + b * 16 * 64);
+    }
+    if constexpr (ISSUE) {
+      // unit phase + 6: phases 0, 1 stage types 2, 3 of the NEXT K tile (other parity), phases 2, 3 types 0, 1 of the one after
+      // (ga / gw point at K tile kt - PAR: the loop advances them once per pair of tiles)
+      if constexpr (PH == 0) issue(std::integral_constant<int, PAR ^ 1>{}, I2{}, std::integral_constant<int, PAR + 1>{});
+      if constexpr (PH == 1) issue(std::integral_constant<int, PAR ^ 1>{}, I3{}, std::integral_constant<int, PAR + 1>{});
+      if constexpr (PH == 2) issue(std::integral_constant<int, PAR>{}, I0{}, std::integral_constant<int, PAR + 2>{});
+      if constexpr (PH == 3) issue(std::integral_constant<int, PAR>{}, I1{}, std::integral_constant<int, PAR + 2>{});
+    }
+    if constexpr (VM >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | VM);       // vmcnt(VM), lgkmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- multiply part: quadrant (mh, nh) = (0,0) (0,1) (1,1) (1,0)
+    constexpr int mh = PH >> 1, nh = (PH == 1 || PH == 2) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[mh][b][nh][a] = jmfma(wf[nh][a][ks], af[b][ks], acc[mh][b][nh][a]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using VN = std::integral_constant<int, -1>;
+  using V8 = std::integral_constant<int, 8>;
+  using V6 = std::integral_constant<int, 6>;
+  using V4 = std::integral_constant<int, 4>;
+  using V2 = std::integral_constant<int, 2>;
+  using V0 = std::integral_constant<int, 0>;
+
+  const int nk = K / 64;                  // K % 128 == 0: an even number of K tiles, at least two
+  issue(I0{}, I0{}, I0{});
+  issue(I0{}, I1{}, I0{});
+  issue(I0{}, I2{}, I0{});
+  issue(I0{}, I3{}, I0{});
+  issue(I1{}, I0{}, I1{});
+  issue(I1{}, I1{}, I1{});
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = static_cast<float>(braw[c][j]);
+    }
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[mh][b][c >> 1][c & 1] = bv;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8): units 0, 1 (and the bias) have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind from here on
+  int kt = 0;
+  for (; kt < nk - 2; kt += 2) {
+    phase(I0{}, I0{}, I1{}, V8{});
+    phase(I0{}, I1{}, I1{}, V8{});
+    phase(I0{}, I2{}, I1{}, V8{});
+    phase(I0{}, I3{}, I1{}, V8{});
+    phase(I1{}, I0{}, I1{}, V8{});
+    phase(I1{}, I1{}, I1{}, V8{});
+    phase(I1{}, I2{}, I1{}, V8{});
+    phase(I1{}, I3{}, I1{}, V8{});
+    ga += 2 * 64 * sizeof(T);
+    gw += 2 * 64 * sizeof(T);
+  }
+  // the last two K tiles: only the last two units are still to be issued
+  phase(I0{}, I0{}, I1{}, V8{});
+  phase(I0{}, I1{}, I1{}, V8{});
+  phase(I0{}, I2{}, I0{}, V6{});
+  phase(I0{}, I3{}, I0{}, V4{});
+  phase(I1{}, I0{}, I0{}, V2{});
+  phase(I1{}, I1{}, I0{}, V0{});
+  phase(I1{}, I2{}, I0{}, VN{});
+  phase(I1{}, I3{}, I0{}, VN{});
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // waves 0-3 meet the last barrier of waves 4-7
+#undef CAIMAN_UNIT
+
+  // epilogue
+  const int NP = N / 64;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int m = m0 + wr * 128 + mh * 64 + b * 16 + r16;
+      const bool live = m < M;
+      T* crow = C + (int64_t)m * N + n0 + wc * 64 + kq * 4;
+      float v[4][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {           // c = nh * 2 + a: 16 columns each
+        v4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = static_cast<T>(acc[mh][b][c >> 1][c & 1][j]);
+          if constexpr (LSE) {
+            v[c][j] = static_cast<float>(o[j]);      // the normaliser is that of the STORED logits
+            mx = fmaxf(mx, v[c][j]);
+          }
+        }
+        if (live) *reinterpret_cast<v4*>(crow + c * 16) = o;
+      }
+      if constexpr (LSE) {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sm += (v[c][j] == mx) ? 1.f : __expf(v[c][j] - mx);
+        sm += __shfl_xor(sm, 16, kWave);
+        sm += __shfl_xor(sm, 32, kWave);
+        if (live && kq == 0) {
+          const int64_t p = (int64_t)m * NP + (n0 >> 6) + wc;
+          pmax[p] = mx;
+          psum[p] = sm;
+        }
+      }
+    }
+}
+
 // row normaliser from the partial pairs: lse = M + log(sum_p psum_p * exp(pmax_p - M)), M = max_p pmax_p.  One wave per row.
 __global__ __launch_bounds__(256) void lse_partials_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                           float* __restrict__ lse, int64_t rows, int NP) {
@@ -268,6 +537,21 @@ int launch_joint_fc(const T* A, const T* W, const T* bias, T* C, float* lse, flo
   const int group = std::max(1, std::min(group_env > 0 ? group_env : (lse ? 8 : 1), tiles_m));
   float* pmax = lse ? ws : nullptr;
   float* psum = lse ? ws + M * NP : nullptr;
+  // CAIMAN_JOINT_KERNEL=ring: the round-3 four-stage ring kernel (A/B only)
+  static const bool ring = std::getenv("CAIMAN_JOINT_KERNEL") != nullptr && std::string(std::getenv("CAIMAN_JOINT_KERNEL")) == "ring";
+  if (!ring) {
+#define CAIMAN_JGEMM8(L, B)                                                                                               \
+  hipLaunchKernelGGL((joint_fc_gemm8_kernel<T, L, B>), dim3((unsigned)tiles), dim3(512), 0, s, A, W, bias, C, pmax, psum, (int)M, \
+                     (int)N, (int)K, tiles_n, tiles_m, group)
+    if (lse) {
+      if (bias) CAIMAN_JGEMM8(true, true); else CAIMAN_JGEMM8(true, false);
+      hipLaunchKernelGGL(lse_partials_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, pmax, psum, lse, M, NP);
+    } else {
+      if (bias) CAIMAN_JGEMM8(false, true); else CAIMAN_JGEMM8(false, false);
+    }
+#undef CAIMAN_JGEMM8
+    return check_launch("joint projection GEMM");
+  }
 #define CAIMAN_JGEMM(L, P)                                                                                                \
   hipLaunchKernelGGL((joint_fc_gemm_kernel<T, L, P>), dim3((unsigned)tiles), dim3(64 * JNW), 0, s, A, W, bias, C, pmax, psum, \
                      (int)M, (int)N, (int)K, tiles_n, tiles_m, group)
