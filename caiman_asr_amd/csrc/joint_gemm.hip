@@ -53,6 +53,26 @@ __device__ __forceinline__ f32x4 jmfma(jfrag<f16_t>::type a, jfrag<f16_t>::type 
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// A register swapped against a copy of itself: the pair holds, in every lane, the value of the lane's own half (lanes 0-31 /
+// 32-63 for swap32, even / odd 16-lane rows for swap16) and that of the other half -- an all-reduce step without LDS.
+// (The two results are copied out of a NON-const vector into plain integers first: __builtin_bit_cast on an element of a
+// const result vector made hipcc, ROCm 7.2, read element 0 twice.)
+struct jpair {
+  float a, b;
+};
+__device__ __forceinline__ jpair jswap32(float x) {
+  const unsigned a = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return jpair{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
+__device__ __forceinline__ jpair jswap16(float x) {
+  const unsigned a = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return jpair{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
+
 constexpr int JBM = 256, JBN = 256, JBK = 32, JNW = 8;
 constexpr int JTM = 8, JTN = 4;   // 16 x 16 blocks of a wave tile: 128 rows, 64 columns
 
@@ -460,45 +480,79 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
   if (wr == 0) __builtin_amdgcn_s_barrier();   // waves 0-3 meet the last barrier of waves 4-7
 #undef CAIMAN_UNIT
 
-  // epilogue
+  // epilogue.  Per block of 16 rows a lane holds, for its row r16, the four-column packets (c, kq): columns c * 16 + kq * 4 .. + 3.
+  // Two register swaps between lane groups (v_permlane32_swap, v_permlane16_swap: a 4 x 4 transpose of packets between the
+  // register index c and the lane group kq) leave it with columns kq * 16 .. + 15 -- 32 contiguous bytes, two 16-byte stores, and
+  // the four lanes of a row cover one full 128-byte line.  The row's (max, sum exp) over the wave's 64 columns is taken on the
+  // values AS STORED; the reference point is the row maximum clamped to +-2e38, so that rows of -inf / +inf need no per-element
+  // special case (exp2(-inf) = 0; +inf - finite = +inf).
+  using u2 = __attribute__((ext_vector_type(2))) unsigned;
+  using u4 = __attribute__((ext_vector_type(4))) unsigned;
   const int NP = N / 64;
+  constexpr float kLog2e = 1.4426950408889634f;
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int m = m0 + wr * 128 + mh * 64 + b * 16 + r16;
       const bool live = m < M;
-      T* crow = C + (int64_t)m * N + n0 + wc * 64 + kq * 4;
+      u2 P[4];
       float v[4][4];
-      float mx = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {           // c = nh * 2 + a: 16 columns each
+      for (int c = 0; c < 4; ++c) {
         v4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           o[j] = static_cast<T>(acc[mh][b][c >> 1][c & 1][j]);
-          if constexpr (LSE) {
-            v[c][j] = static_cast<float>(o[j]);      // the normaliser is that of the STORED logits
-            mx = fmaxf(mx, v[c][j]);
-          }
+          if constexpr (LSE) v[c][j] = static_cast<float>(o[j]);
         }
-        if (live) *reinterpret_cast<v4*>(crow + c * 16) = o;
+        P[c] = __builtin_bit_cast(u2, o);
       }
       if constexpr (LSE) {
-        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[0][3]));
+#pragma unroll
+        for (int c = 1; c < 4; ++c) mx = fmaxf(fmaxf(mx, fmaxf(v[c][0], v[c][1])), fmaxf(v[c][2], v[c][3]));
+        {                                               // over the four lanes (kq) that share the row
+          const jpair h = jswap32(mx);
+          mx = fmaxf(h.a, h.b);
+          const jpair q = jswap16(mx);
+          mx = fmaxf(q.a, q.b);
+        }
+        mx = fminf(fmaxf(mx, -2e38f), 2e38f);
+        const float nmx = -mx * kLog2e;
         float sm = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sm += (v[c][j] == mx) ? 1.f : __expf(v[c][j] - mx);
-        sm += __shfl_xor(sm, 16, kWave);
-        sm += __shfl_xor(sm, 32, kWave);
+          for (int j = 0; j < 4; ++j) sm += __builtin_amdgcn_exp2f(__builtin_fmaf(v[c][j], kLog2e, nmx));
+        {
+          const jpair h = jswap32(sm);
+          sm = h.a + h.b;
+          const jpair q = jswap16(sm);
+          sm = q.a + q.b;
+        }
         if (live && kq == 0) {
           const int64_t p = (int64_t)m * NP + (n0 >> 6) + wc;
           pmax[p] = mx;
           psum[p] = sm;
         }
+      }
+      // packets (c, kq) -> (kq, c)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        auto s02 = __builtin_amdgcn_permlane32_swap(P[0][d], P[2][d], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(P[1][d], P[3][d], false, false);
+        auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        P[0][d] = t01[0];
+        P[1][d] = t01[1];
+        P[2][d] = t23[0];
+        P[3][d] = t23[1];
+      }
+      if (live) {
+        T* crow = C + (int64_t)m * N + n0 + wc * 64 + kq * 16;
+        *reinterpret_cast<u4*>(crow) = u4{P[0][0], P[0][1], P[1][0], P[1][1]};
+        *reinterpret_cast<u4*>(crow + 8) = u4{P[2][0], P[2][1], P[3][0], P[3][1]};
       }
     }
 }
@@ -584,7 +638,7 @@ extern "C" int caiman_joint_fc_forward(const void* A, const void* W, const void*
                (long long)N, (long long)K, dtype);
   CAIMAN_CHECK(A && W && C && (lse == nullptr || workspace != nullptr), "joint_fc_forward: null pointer");
   auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-  CAIMAN_CHECK(al(A, 16) && al(W, 16) && al(C, 8) && (!bias || al(bias, 8)), "joint_fc_forward: operands 16-byte, C / bias 8-byte aligned");
+  CAIMAN_CHECK(al(A, 16) && al(W, 16) && al(C, 16) && (!bias || al(bias, 8)), "joint_fc_forward: operands and C 16-byte, bias 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == CAIMAN_BF16)
     return launch_joint_fc<bf16_t>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)C, lse, workspace, M, N, K, s);

@@ -57,9 +57,10 @@ def lib_fwd():
 
 
 res = {"rows": M, "K": K, "N": N, "tflop": 2.0 * M * N * K / 1e12}
-rows = {k: [] for k in ("hand_fwd_lse", "lib_fwd", "lib_fwd_lse", "hand_dx", "lib_dx", "hand_dw", "lib_dw")}
+rows = {k: [] for k in ("hand_fwd_lse", "hand_fwd", "lib_fwd", "lib_fwd_lse", "hand_dx", "lib_dx", "hand_dw", "lib_dw")}
 for _ in range(args.rounds):
     rows["hand_fwd_lse"].append(timed(lambda: _joint_gemm(a, w, b, True)))
+    rows["hand_fwd"].append(timed(lambda: _joint_gemm(a, w, b, False)))
     rows["lib_fwd"].append(timed(lambda: torch.nn.functional.linear(a, w, b)))
     rows["lib_fwd_lse"].append(timed(lib_fwd))
     rows["hand_dx"].append(timed(lambda: _joint_gemm(dy, wt, None, False)))
