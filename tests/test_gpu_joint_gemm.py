@@ -24,11 +24,13 @@ def _run(a, w, bias, want_lse):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,bias,lse", [
-    (1000, 512, 256, True, True),        # ragged last M tile, two N tiles, two ring rounds
+    (1000, 512, 256, True, True),        # ragged last M tile, two N tiles, the shortest K (four K tiles: first + last pair only)
     (257, 8704, 768, True, True),        # the joint projection's own N and K; one full and one 1-row tile
-    (256, 256, 128, False, True),        # a single tile, the shortest K the ring takes (4 stages)
-    (4101, 768, 8704, False, False),     # the input gradient dY . W: N = 768, K = 8704 (272 stages)
+    (256, 256, 256, False, True),        # a single tile
+    (193, 256, 384, True, True),         # one tile whose second A half (rows 64 ..) ends inside the tile, its fourth not at all
+    (4101, 768, 8704, False, False),     # the input gradient dY . W: N = 768, K = 8704 (136 K tiles)
     (3000, 17408, 1024, True, True),     # large-196M: V = 17 408, joint_n_hid = 1024
+    (70000, 1024, 512, True, True),      # 1096 tiles on 256 persistent workgroups: 4-5 tiles each, ragged last M tile
 ])
 def test_joint_fc_gemm_matches_fp32_product_and_row_lse(dtype, M, N, K, bias, lse):
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
@@ -75,7 +77,7 @@ def test_joint_fc_gemm_is_deterministic_over_repeated_launches():
 
 
 def test_nan_rows_propagate_to_their_normalisers_only():
-    M, N, K = 300, 512, 128
+    M, N, K = 300, 512, 256
     a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
     a[7, 3] = float("nan")
     w = torch.randn(N, K, device=DEV).to(torch.bfloat16)
@@ -86,7 +88,7 @@ def test_nan_rows_propagate_to_their_normalisers_only():
 
 def test_model_step_with_the_handwritten_joint_projection_equals_the_library_path(monkeypatch):
     """One bf16 training step of the golden mini model... its joint sizes (V = 29, Hj = 32) are outside the kernel's
-    geometry, so a model with N % 256 == 0 and K % 128 == 0 is built here: loss and gradients with CAIMAN_JOINT_GEMM on
+    geometry, so a model with N % 256 == 0 and K = 256 is built here: loss and gradients with CAIMAN_JOINT_GEMM on
     and off agree to the storage resolution, and the loss really took the normalisers from the projection."""
     from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, get_packing_meta_data
     from caiman_asr_amd.rnnt.model import RNNT
@@ -95,7 +97,7 @@ def test_model_step_with_the_handwritten_joint_projection_equals_the_library_pat
 
     cfg = dict(in_feats=48, enc_n_hid=128, enc_pre_rnn_layers=1, enc_post_rnn_layers=1, enc_stack_time_factor=2,
                enc_dropout=0.0, enc_batch_norm=False, enc_freeze=False, pred_n_hid=128, pred_rnn_layers=1, pred_dropout=0.0,
-               pred_batch_norm=False, joint_n_hid=128, joint_dropout=0.0, joint_net_lr_factor=1.0, joint_apex_transducer="pack",
+               pred_batch_norm=False, joint_n_hid=256, joint_dropout=0.0, joint_net_lr_factor=1.0, joint_apex_transducer="pack",
                joint_apex_relu_dropout=True, forget_gate_bias=1.0, custom_lstm=True, quantize=False, enc_rw_dropout=0.0,
                pred_rw_dropout=0.0)
     V, B, T = 512, 6, 24
