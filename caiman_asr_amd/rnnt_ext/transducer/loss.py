@@ -46,8 +46,20 @@ _latest_row_lse = None
 
 
 def offer_row_lse(logits: torch.Tensor, lse: torch.Tensor):
+    """Called by the projection's forward.  The entry holds a WEAK reference to the logits' storage: once that memory is
+    released (a projection whose output never reached a loss: evaluation, an exception), the entry is dead even if the
+    allocator hands the same address, shape and dtype to a later tensor."""
     global _latest_row_lse
-    _latest_row_lse = (logits.data_ptr(), tuple(logits.shape), logits.dtype, logits._version, lse)
+    import weakref
+
+    _latest_row_lse = (logits.data_ptr(), tuple(logits.shape), logits.dtype, logits._version, lse,
+                       weakref.ref(logits.untyped_storage()))
+
+
+def clear_row_lse():
+    """Every projection forward starts with this (also the library path, which offers nothing)."""
+    global _latest_row_lse
+    _latest_row_lse = None
 
 
 def take_row_lse(x: torch.Tensor):
@@ -56,7 +68,9 @@ def take_row_lse(x: torch.Tensor):
     ent, _latest_row_lse = _latest_row_lse, None
     if (ent is not None and ent[0] == x.data_ptr() and ent[1] == tuple(x.shape) and ent[2] == x.dtype
             and ent[3] == x._version and ent[4].numel() == x.numel() // x.shape[-1]):
-        return ent[4]
+        st = ent[5]()
+        if st is not None and st.data_ptr() == x.untyped_storage().data_ptr():
+            return ent[4]
     return None
 
 

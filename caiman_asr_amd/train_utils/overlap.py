@@ -86,9 +86,11 @@ def _weight_gradient(dy2, x2):
 
 
 # The joint projection on the hand-written MFMA GEMM (csrc/joint_gemm.hip): forward with the row log-sum-exp of the logits in
-# its epilogue (the loss then skips its own pass over the 5.3 GB of logits), input gradient with the same kernel.
-# CAIMAN_JOINT_GEMM: "0" library GEMMs (F.linear / torch.mm), "1" forward + input gradient, "fwd" forward only.
-JOINT_GEMM = __import__("os").environ.get("CAIMAN_JOINT_GEMM", "0")
+# its epilogue (the loss then skips its own pass over the 5.3 GB of logits), input gradient with the same kernel.  Default
+# since round 4 (8-phase main loop, persistent workgroups: forward + LSE 4.0 ms against the library's 3.4 + 0.9, input
+# gradient 2.8 against 2.95 at 304 000 x 768 x 8704).
+# CAIMAN_JOINT_GEMM: "1" forward + input gradient (default), "fwd" forward only, "0" library GEMMs (F.linear / torch.mm).
+JOINT_GEMM = __import__("os").environ.get("CAIMAN_JOINT_GEMM", "1")
 
 
 def _joint_gemm(a2, w, bias, want_lse):
@@ -202,15 +204,16 @@ class _LinearTransposedBackward(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias):
+        from caiman_asr_amd.rnnt_ext.transducer.loss import clear_row_lse, offer_row_lse
+
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        clear_row_lse()            # a projection that never reached a loss must not leave its normalisers behind
         if JOINT_GEMM != "0" and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             x2 = x.reshape(-1, x.shape[-1])
             out = _joint_gemm(x2 if x2.is_contiguous() else x2.contiguous(), weight.to(x.dtype).contiguous(),
                               None if bias is None else bias.to(x.dtype).contiguous(), want_lse=True)
             if out is not None:
-                from caiman_asr_amd.rnnt_ext.transducer.loss import offer_row_lse
-
                 c, lse = out
                 c = c.view(*x.shape[:-1], weight.shape[0])
                 offer_row_lse(c, lse)      # the loss picks the normalisers up instead of reading the logits again
