@@ -39,7 +39,7 @@ import torch.distributed as dist
 FRAME_SECONDS = 0.03  # 10 ms hop x 3 frame subsampling (training/caiman_asr_train/utils/frame_width.py)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
-PMC_FILE = "r03_base_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
+PMC_FILE = "r04a_base_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 BASE_RNNT = dict(  # training/configs/base-8703sp.yaml:73-94
@@ -83,6 +83,19 @@ def make_batches(n_batches, batch_size, seed, n_mels=80):
         txt = torch.randint(0, N_CLASSES - 1, (batch_size, U), generator=g)
         batches.append((feats, torch.tensor(frames), txt, torch.tensor(ntok)))
     return batches
+
+
+def make_pcm(frames, seed):
+    """Synthetic 16 kHz PCM [B, max_samples] f32 whose log-mel has exactly `frames` frames per utterance with the frontend's
+    geometry (25 ms window, 10 ms hop, 15 ms of initial padding: n_frames = n_samples // 160): what the data loader leaves
+    resident in HBM for the frontend kernels (training/caiman_asr_train/data/dali/pipeline.py:359-470 runs them on the
+    training GPU too)."""
+    samples = frames * 160
+    g = torch.Generator().manual_seed(int(seed))
+    pcm = 0.1 * torch.randn(len(frames), int(samples.max()), generator=g)
+    for i, n in enumerate(samples):
+        pcm[i, int(n):] = 0
+    return pcm, samples
 
 
 def _cpu_time(fn, budget_s, max_iters=50):
@@ -294,6 +307,9 @@ def main():
     ap.add_argument("--debug-steps", action="store_true", help="sync + log wall time of every step (perturbs timing)")
     ap.add_argument("--sequential-augment", action="store_true",
                     help="SpecAugment, FrameSplicing and PermuteAudio as separate torch modules instead of the fused kernel (A/B)")
+    ap.add_argument("--features-resident", action="store_true",
+                    help="start the timed step from log-mel features resident in HBM (rounds 1-3) instead of resident 16 kHz PCM: "
+                         "leaves caiman_logmel_forward + caiman_mel_normalize out of the clock (A/B)")
     ap.add_argument("--feed", action="store_true",
                     help="after the timed loop, time the same steps again WHILE the data feed (AudioBatchLoader: 8 FLAC decode "
                          "threads, side-stream log-mel / normalise / splice kernels) produces one batch per step (N = 1 only)")
@@ -329,6 +345,7 @@ def main():
 
     from caiman_asr_amd import _lib
     from caiman_asr_amd.data.features import FrameSplicing, SpecAugment, augment_splice_permute
+    from caiman_asr_amd.data.frontend import LogMelFrontend, MelFeatNormalizer, NormType, norm_ramp_params
     from caiman_asr_amd.rnnt.loss import ApexTransducerLoss, LossModifiers, get_packing_meta_data
     from caiman_asr_amd.rnnt.model import RNNT
     from caiman_asr_amd.train_utils.distributed import FlatGradReducer, broadcast_parameters
@@ -364,8 +381,21 @@ def main():
 
     n_distinct = min(args.steps + args.warmup, 12)
     host_batches = make_batches(n_distinct, args.batch, seed=1 + rank)
-    # inputs resident in HBM before the timed region
-    dev_batches = [(f.to(dev), fl, t.to(dev), tl) for f, fl, t, tl in host_batches]
+    # inputs resident in HBM before the timed region: 16 kHz PCM (default: the whole north-star step is on the clock, log-mel
+    # frontend and mel normalisation included) or, with --features-resident, the log-mel features themselves
+    if args.features_resident:
+        dev_batches = [(f.to(dev), fl, t.to(dev), tl) for f, fl, t, tl in host_batches]
+        frontend = normalizer = None
+    else:
+        dev_batches = []
+        for j, (f, fl, t, tl) in enumerate(host_batches):
+            pcm, samples = make_pcm(fl, seed=977 * (1 + rank) + j)
+            dev_batches.append(((pcm.to(dev), samples.to(dev).to(torch.int32)), fl, t.to(dev), tl))
+        frontend = LogMelFrontend(device=str(dev))
+        # blended dataset / utterance statistics on the reference's ramp (mel_normalization.py:85-118; synthetic dataset stats)
+        ramp = norm_ramp_params(NormType.BLENDED_STATS, 1632, 18000, 10880)
+        normalizer = MelFeatNormalizer(torch.zeros(80), torch.ones(80), ramp[0], ramp[1], starting_ratio=0.25)
+        normalizer.means, normalizer.stddevs = normalizer.means.to(dev), normalizer.stddevs.to(dev)
 
     executed = [0]   # steps run in this process (pre-warm + warm-up + timed [+ feed]): what a profiler's trace holds
 
@@ -374,6 +404,11 @@ def main():
         feats, feat_lens_h, txt, txt_lens_h = dev_batches[i % n_distinct]
         lr_policy(optimizer, initial_lrs, 4e-4, global_step, 1632, 18000, 10880)
         feat_lens_d = feat_lens_h.to(dev, non_blocking=True)
+        if frontend is not None:       # PCM -> log-mel [B, 80, T] -> normalised: the two frontend kernels, on the step's stream
+            pcm, samples_d = feats
+            feats, _ = frontend(pcm, samples_d, seed=global_step + 1)
+            normalizer.step(global_step)
+            feats = normalizer(feats, feat_lens_d)
         if args.sequential_augment:                        # the three feature processors one at a time (A/B)
             x, _ = spec((feats, feat_lens_d))
             x, lens_h = splice((x, feat_lens_h))
@@ -392,7 +427,7 @@ def main():
         if reducer is not None:
             reducer.finish()
         optimizer.step(zero_grad=True)
-        return loss.detach(), float(lens_h.sum()) * FRAME_SECONDS, meta["packed_batch"]
+        return loss.detach(), float(lens_h.sum()) * FRAME_SECONDS, meta["packed_batch"], int(txt_lens_h.sum()) + len(txt_lens_h)
 
     if args.main_priority != 0:
         # The critical path (LSTM step kernels, joint backward) is a chain of short kernels; the side streams carry
@@ -433,7 +468,7 @@ def main():
     torch.cuda.synchronize()
     log(f"model + {n_distinct} batches resident; warm-up")
     for i in range(args.warmup):
-        last_loss, _, _ = step(i, i)
+        last_loss = step(i, i)[0]
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
         if i == 0:
@@ -452,7 +487,7 @@ def main():
         _lib.timing.enabled = True
         _lib.timing.sample_every = {"lstm_fwd": 16, "lstm_bwd": 16}   # see _lib._Timing: every bracket would cost 13 %
         _lib.timing.reset()
-    audio_s, cells = 0.0, 0
+    audio_s, cells, pred_tokens = 0.0, 0, 0
     in_flight = []   # the host may run at most two steps ahead of the device (a real loop reads the loss now and then);
     #                  unbounded run-ahead makes the allocator hold every queued step's activations at once
     host_wait = host_issue = 0.0   # host blocked on the run-ahead limit | host queuing a step's commands
@@ -463,7 +498,8 @@ def main():
             in_flight.pop(0).synchronize()
         tq = time.perf_counter()
         host_wait += tq - ts
-        last_loss, a, c = step(args.warmup + i, args.warmup + i)
+        last_loss, a, c, ntok = step(args.warmup + i, args.warmup + i)
+        pred_tokens += ntok
         host_issue += time.perf_counter() - tq
         done = torch.cuda.Event()
         done.record(main_stream if args.main_priority != 0 else torch.cuda.current_stream())
@@ -507,17 +543,44 @@ def main():
                        "global_batch": args.batch * world, "utterance_seconds": "clip(N(12.3,3.8),1,16.7)",
                        "parallelism": f"dp{world}", "final_loss": loss_val,
                        "audio_seconds_per_step": audio_total / args.steps,
-                       "timed_step": "on-device SpecAugment + frame splicing + fwd + loss + bwd + (gradient all-reduce) + "
-                                     "LAMB/EMA; inputs are log-mel features [B,80,T] resident in HBM: the log-mel "
-                                     "frontend / audio decode run outside the timed step (tools/feed_bench.py measures "
-                                     "the feed separately)"},
+                       "timed_step": ("log-mel frontend + mel normalisation (from 16 kHz PCM resident in HBM) + on-device SpecAugment + "
+                                      "frame splicing + fwd + loss + bwd + (gradient all-reduce) + LAMB/EMA"
+                                      if frontend is not None else
+                                      "on-device SpecAugment + frame splicing + fwd + loss + bwd + (gradient all-reduce) + "
+                                      "LAMB/EMA; --features-resident: inputs are log-mel features [B,80,T] resident in HBM, the "
+                                      "log-mel frontend is outside the timed step")},
         }
         # how close the step is to being launch-bound: the host thread needs `issue` ms to queue a step's commands and
         # waits `wait_for_device` ms per step for the device to catch up (run-ahead limit of two steps)
         out["host_ms_per_step"] = {"issue": round(host_issue / args.steps * 1e3, 2),
                                    "wait_for_device": round(host_wait / args.steps * 1e3, 2)}
+        # ---- the whole step against the chip (SURVEY section 8(d) formulas; training = 3 x forward for the GEMM terms):
+        # encoder 2.748 GFLOP per audio-second, prediction + joint_pred 9.175 MFLOP per token (+ SOS), joint 13.369 MFLOP per
+        # lattice cell (large-196M: 6.128 / 20.45 / 35.65).  Algorithmic HBM bytes: the logits cross HBM six times per cell
+        # (joint_fc write, LSE read, loss-backward read + write, dX read, dW read: 6 V s) unless a pass is fused away, the
+        # optimiser moves 14 x 4 P bytes (three passes over five fp32 arenas); LSTM activations are 2 % of that and left out.
+        gf_audio, mf_tok, mf_cell = (2.748, 9.175, 13.369) if args.model == "base" else (6.128, 20.45, 35.65)
+        flop_step = 3.0 * (gf_audio * 1e9 * audio_s + mf_tok * 1e6 * pred_tokens + mf_cell * 1e6 * cells) / args.steps
+        bytes_step = (6.0 * N_CLASSES * 2 * cells / args.steps) + 14 * 4 * int(optimizer.flat_g.numel())
+        step_s = elapsed / args.steps
+        out["roofline_step"] = {"flop_per_step": flop_step, "tflops": flop_step / step_s / 1e12, "peak_tflops": MFMA_PEAK_TFLOPS,
+                                "mfma_frac": flop_step / step_s / 1e12 / MFMA_PEAK_TFLOPS,
+                                "hbm_bytes_per_step": bytes_step, "hbm_gbs": bytes_step / step_s / 1e9, "peak_gbs": HBM_PEAK_GBS,
+                                "hbm_frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS,
+                                "per_gpu": True,
+                                "note": "algorithmic FLOP and HBM bytes of ONE rank's step (SURVEY 8(d) per-unit figures x the "
+                                        "audio-seconds, tokens and lattice cells of the timed steps) over the measured step time; the "
+                                        "step is a blend of MFMA-bound GEMMs, HBM-bound loss / optimiser passes and a latency-bound "
+                                        "recurrence, so neither fraction can reach 1"}
         if world > 1:
             out["allreduce_exposed_ms"] = exposed_ms    # per step, max over ranks: compute stream idle in reducer.finish()
+            # model beside the measurement: ring all-reduce of 4 P bytes over one xGMI link per direction (153 GB/s), of which
+            # the weight-gradient tail of the backward pass (the only span in which collectives share the chip with compute:
+            # fence_collectives keeps them off while a recurrence runs) hides `tail_ms`
+            ring_ms = 2.0 * (world - 1) / world * int(optimizer.flat_g.numel()) * 4 / 153e9 * 1e3
+            tail_ms = 3.8 if args.model == "base" else 9.7     # joint_fc weight gradient, profiles/r04*_summary.md
+            out["allreduce_exposed_ms_model"] = {"ring_ms": ring_ms, "hidden_under_weight_gradient_tail_ms": tail_ms,
+                                                 "exposed_ms": max(0.0, ring_ms - tail_ms), "link_gbs": 153.0}
             out["gradient_exchange"] = {"bytes_per_step": int(optimizer.flat_g.numel()) * 4, "collectives_per_step": len(reducer.buckets),
                                         "backend": dist.get_backend()}
         if rehearsal:
