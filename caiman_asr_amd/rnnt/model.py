@@ -122,8 +122,8 @@ class RNNT(nn.Module):
         dec = self.prediction["dec_rnn"]
         if dec.dropout:
             yp = dec.dropout(yp)
-        f = self.joint_enc(yt.transpose(0, 1))
-        g = self.joint_pred(yp.transpose(0, 1))
+        f = self._joint_in(self.joint_enc, yt.transpose(0, 1))
+        g = self._joint_in(self.joint_pred, yp.transpose(0, 1))
         g_lens = y_lens + 1
         new_enc = EncoderState(pre_rnn=maybe_get_last_nonpadded(all_pre, x_lens),
                                post_rnn=maybe_get_last_nonpadded(all_post, lens2))
@@ -195,17 +195,27 @@ class RNNT(nn.Module):
             y, lens2, all_pre, all_post, _, _ = merged
             pre_last = maybe_get_last_nonpadded(all_pre, x_lens)
             post_last = maybe_get_last_nonpadded(all_post, lens2)
-            return self.joint_enc(y.transpose(0, 1)), lens2, EncoderState(pre_rnn=pre_last, post_rnn=post_last)
+            return self._joint_in(self.joint_enc, y.transpose(0, 1)), lens2, EncoderState(pre_rnn=pre_last, post_rnn=post_last)
         x, _, all_pre = self.encoder["pre_rnn"](x, enc_state.pre_rnn if enc_state else None)
         pre_last = maybe_get_last_nonpadded(all_pre, x_lens)
         x, x_lens = self.encoder["stack_time"](x, x_lens)
         x, _, all_post = self.encoder["post_rnn"](x, enc_state.post_rnn if enc_state else None)
         post_last = maybe_get_last_nonpadded(all_post, x_lens)
-        x = self.joint_enc(x.transpose(0, 1))
+        x = self._joint_in(self.joint_enc, x.transpose(0, 1))
         new_state = None
         if all_pre is not None and all_post is not None:
             new_state = EncoderState(pre_rnn=pre_last, post_rnn=post_last)
         return x, x_lens, new_state
+
+    def _joint_in(self, lin, x):
+        """joint_enc / joint_pred (torch.nn.Linear in the reference, model.py:82-83 there): on the GPU in training the same
+        product with fp32 parameter gradients (train_utils/overlap.py::linear_f32_grads); plain module call otherwise."""
+        if x.is_cuda and torch.is_grad_enabled() and (lin.weight.requires_grad or x.requires_grad):
+            from caiman_asr_amd.train_utils.overlap import linear_f32_grads
+
+            return linear_f32_grads(x, lin.weight, lin.bias)
+        # contiguous rows: torch's linear fuses the bias into the GEMM only then (else: a second rounding in the 16-bit type)
+        return lin(x.contiguous() if x.is_cuda else x)
 
     def predict(self, y, pred_state=None, add_sos: bool = True, special_sos=None):
         """y [B,U] (or None for a single zero-embedding step) -> g [B,U+1,Hj], (h,c), all states."""
@@ -224,7 +234,7 @@ class RNNT(nn.Module):
             y = torch.cat([start, y], dim=1).contiguous()
         y = y.transpose(0, 1)
         g, hid, all_hid = self.prediction["dec_rnn"](y, pred_state)
-        g = self.joint_pred(g.transpose(0, 1))
+        g = self._joint_in(self.joint_pred, g.transpose(0, 1))
         return g, hid, all_hid
 
     def joint(self, f, g, f_len=None, g_len=None, batch_offset=None, packed_batch: Optional[int] = None):

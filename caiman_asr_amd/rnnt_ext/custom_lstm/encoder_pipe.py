@@ -557,7 +557,7 @@ class EncoderPipeFunction(torch.autograd.Function):
         def tn(dg3, x3):
             """dg3 [P, rows, 4H]^T . x3 [P, rows, K] -> [P, 4H, K]: the hand-written kernel where it applies, else the library"""
             out = overlap.wgrad_tn(dg3, x3, only_if_faster=True) if WGRAD_TN else None
-            return out if out is not None else torch.bmm(dg3.transpose(1, 2), x3)
+            return out if out is not None else torch.bmm(dg3.transpose(1, 2), x3, out_dtype=torch.float32)   # fp32 products, like the kernel's
 
         def rows3(t, first, count, skip, T):
             """layers [first, first + count) of t [layers, T (+ 1), B, H], steps [skip, skip + T) -> [count, T * B, H] without
@@ -588,7 +588,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             else:
                 post_R = tn(dgb, rows3(Yb, 0, Lb, 0, T2))
                 post_W = tn(dgb[1:], xin)
-            post_b = None if fused_db else dgb.sum(1)
+            post_b = None if fused_db else dgb.sum(1, dtype=torch.float32)
         # pre layers: dR of all La layers and dW of layers 1 .. La - 1 have one shape (layer 0's dW has K = in_feats): one
         # launch of the weight-gradient kernel where its cost model prefers that to one product at a time
         pre_R = pre_W = None
@@ -613,12 +613,12 @@ class EncoderPipeFunction(torch.autograd.Function):
                 gW = post_W[m - 1] if m >= 1 else tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0]
                 g4 = [gW, post_R[m], dB, dB]
             elif pre_R is not None and l < La:
-                dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)
+                dB = dbias[l, :4 * hl] if fused_db else dg.sum(0, dtype=torch.float32)
                 gW = pre_W[l - 1] if l >= 1 else tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0]
                 g4 = [gW, pre_R[l], dB, dB]
             else:
                 yprev = (Ya[l, :T1] if l < La else Yb[l - La, :T2] if l < Le else Yp[l - Le, :Tp]).reshape(T * B, hl)
-                dB = dbias[l, :4 * hl] if fused_db else dg.sum(0)
+                dB = dbias[l, :4 * hl] if fused_db else dg.sum(0, dtype=torch.float32)
                 g4 = [tn(dg.unsqueeze(0), layer_input(l).unsqueeze(0))[0], tn(dg.unsqueeze(0), yprev.unsqueeze(0))[0], dB, dB]
             if direct:
                 ps = ctx.params[4 * l:4 * l + 4]

@@ -14,52 +14,55 @@ from torch import Tensor as Ten
 import caiman_asr_amd.rnnt_ext.cuda.lstm as lstm_cu
 
 
+def _state_rows(first: Ten, steps: int, width: int, dtype) -> Ten:
+    """[steps + 1, B, width] buffer of one recurrent state, row 0 = the initial state"""
+    rows = torch.empty((steps + 1, first.shape[0], width), dtype=dtype, device=first.device)
+    rows[0].copy_(first)
+    return rows
+
+
 class Function(torch.autograd.Function):
-    """One LSTM layer over a whole sequence: returns (y[1:], c[1:]); gradients flow to x and
-    the four parameters only (no gradient to y0/c0: truncated BPTT, lstm.py:144)."""
+    """One LSTM layer over a whole sequence (the operator behind rnnt_ext.custom_lstm.lstm.Function of the reference,
+    training/lib/src/rnnt_ext/custom_lstm/lstm.py:11-144): (y0, c0, x, W, R, bW, bR) -> (y[1..T], c[1..T]).  The input
+    projection of all timesteps is one library GEMM whose output type (the autocast type) is the type of everything the
+    recurrence stores; the recurrence itself is `lstm_fused_fwd / _bwd` (csrc/lstm.hip).  Gradients go to x and the four
+    parameters -- not to the initial state (truncated back-propagation through time) -- and the parameter gradients
+    leave their GEMMs / sums as fp32 whatever the storage type."""
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, lstm_fused_fwd, lstm_fused_bwd, y0: Ten, c0: Ten, x: Ten, W: Ten, R: Ten,
                 bW: Ten, bR: Ten) -> Tuple[Ten, Ten]:
-        T, B = x.shape[0], x.shape[1]
-        x_flat = x.flatten(0, 1)
-        # every timestep's x·Wᵀ + (bW + bR) in one GEMM (lstm.py:51-55); under autocast this
-        # produces the reduced-precision gate dtype that everything below inherits.
-        gates = torch.addmm(bW + bR, x_flat, W.t()).view(T, B, W.shape[0])
-        x_flat.requires_grad = x.requires_grad
-
-        shape = list(x.shape)
-        shape[-1] = W.shape[0] // 4
-        shape[0] += 1
-        y = torch.empty(shape, dtype=gates.dtype, device=x.device)
-        c = torch.empty(shape, dtype=gates.dtype, device=x.device)
-        y[0].copy_(y0)
-        c[0].copy_(c0)
-        Rp = R.type(dtype=gates.dtype)
-
-        lstm_fused_fwd(Rp, gates, c, y)
-
-        ctx.save_for_backward(W, Rp, x_flat, y[:-1].flatten(0, 1), c, gates)
-        ctx.lstm_fused_bwd = lstm_fused_bwd
-        return y[1:], c[1:]
+        steps, hidden = x.shape[0], R.shape[1]
+        x2 = x.flatten(0, 1)
+        pre = torch.addmm(bW + bR, x2, W.t()).view(steps, x.shape[1], 4 * hidden)   # x_t W^T + b for every t at once
+        store = pre.dtype
+        y_rows, c_rows = _state_rows(y0, steps, hidden, store), _state_rows(c0, steps, hidden, store)
+        R_store = R.to(store)
+        lstm_fused_fwd(R_store, pre, c_rows, y_rows)        # pre becomes the activated gates, rows 1.. of y / c are filled
+        ctx.x_needs_grad = x.requires_grad
+        ctx.save_for_backward(W, R_store, x2, y_rows, c_rows, pre)
+        ctx.kernel = lstm_fused_bwd
+        return y_rows[1:], c_rows[1:]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, delta: Ten, *_):
-        W, Rp, x, y, c, gates = ctx.saved_tensors
-        assert delta.dtype == Rp.dtype
-        dG = torch.empty_like(gates, memory_format=torch.contiguous_format)
-        ctx.lstm_fused_bwd(Rp, gates, c, delta, dG)
-
-        dB = dG.sum([0, 1])
-        dG2 = dG.flatten(0, 1)
-        dX = torch.matmul(dG2, W.to(dG2.dtype)).view(delta.shape[0], -1, x.shape[1]) if x.requires_grad else None
-        dW = torch.matmul(dG2.t(), x.detach().to(dG2.dtype))
-        dR = torch.matmul(dG2.t(), y)
-        return None, None, None, None, dX, dW, dR, dB.unsqueeze(0), dB.unsqueeze(0)
+        W, R_store, x2, y_rows, c_rows, gates = ctx.saved_tensors
+        if delta.dtype != R_store.dtype:
+            raise AssertionError("gradient of the layer output must have the storage type of the layer")
+        dG = torch.empty(gates.shape, dtype=gates.dtype, device=gates.device)
+        ctx.kernel(R_store, gates, c_rows, delta, dG)
+        dG2 = dG.view(-1, dG.shape[-1])
+        low = dG2.is_cuda and dG2.dtype in (torch.float16, torch.bfloat16)
+        f32 = dict(out_dtype=torch.float32) if low else {}
+        db = dG2.sum(0, dtype=torch.float32 if low else dG2.dtype).unsqueeze(0)
+        dx = torch.mm(dG2, W.to(dG2.dtype)).view(delta.shape[0], delta.shape[1], -1) if ctx.x_needs_grad else None
+        dw = torch.mm(dG2.t(), x2.detach().to(dG2.dtype), **f32)
+        dr = torch.mm(dG2.t(), y_rows[:-1].view(-1, y_rows.shape[-1]), **f32)
+        return None, None, None, None, dx, dw, dr, db, db
 
 
 class HardLayer(torch.nn.Module):
@@ -169,23 +172,19 @@ class CustomLSTM(torch.nn.Module):
                                                         *params)
             return y, (all_h[:, -1], all_c[:, -1]), (all_h, all_c)
 
-        h_fl, c_fl, all_h_fl, all_c_fl = [], [], [], []
-        x = None
-        for i, layer in enumerate(self.layers):
-            layer_input = input if i == 0 else self.drop_function(x)
+        # one layer after the other (fp32 / fp64 inputs, recurrent-weight dropout, stacks the pipeline does not take)
+        depth, (steps, batch) = self.num_layers, input.shape[:2]
+        every_h = every_c = None
+        feed = input
+        for idx, layer in enumerate(self.layers):
             if state is None:
-                shape = list(input.shape[1:])
-                shape[-1] = self.hidden_size
-                h_0 = torch.zeros(shape, device=input.device, dtype=input.dtype)
-                c_0 = torch.zeros(shape, device=input.device, dtype=input.dtype)
+                first = tuple(torch.zeros((batch, self.hidden_size), device=input.device, dtype=input.dtype) for _ in range(2))
             else:
-                h_0 = state[0][i].detach()
-                c_0 = state[1][i].detach()
-            h, c = layer(layer_input, (h_0, c_0))
-            h_fl.append(h[-1])
-            c_fl.append(c[-1])
-            all_h_fl.append(h)
-            all_c_fl.append(c)
-            x = h
-        return (x, (torch.stack(h_fl, dim=0), torch.stack(c_fl, dim=0)),
-                (torch.stack(all_h_fl, dim=0), torch.stack(all_c_fl, dim=0)))
+                first = (state[0][idx].detach(), state[1][idx].detach())
+            h, c = layer(feed if idx == 0 else self.drop_function(feed), first)
+            if every_h is None:      # allocated in the type the first layer stores its rows in
+                every_h = h.new_empty((depth, steps, batch, self.hidden_size))
+                every_c = c.new_empty((depth, steps, batch, self.hidden_size))
+            every_h[idx], every_c[idx] = h, c
+            feed = h
+        return feed, (every_h[:, -1], every_c[:, -1]), (every_h, every_c)

@@ -273,9 +273,12 @@ class StackFunction(torch.autograd.Function):
                 xin = x.detach().flatten(0, 1).to(dt)
             else:
                 xin = (YM[l - 1] if drop > 0.0 else Y[l - 1, 1:]).reshape(T * B, H)
-            dB = _unperm_rows(dbias[l] if fused_db else dg.sum(0), H)
-            return [_unperm_rows(torch.matmul(dg.t(), xin), H),
-                    _unperm_rows(torch.matmul(dg.t(), Y[l, :-1].reshape(T * B, H)), H), dB, dB]
+            # parameter gradients leave as fp32 products (a 16-bit library output would round every element once more:
+            # up to 4e-3 of the tensor's range, profiles/r04_bf16_residual.md)
+            f32 = dict(out_dtype=torch.float32) if dg.dtype in (torch.float16, torch.bfloat16) else {}
+            dB = _unperm_rows(dbias[l] if fused_db else dg.sum(0, dtype=torch.float32), H)
+            return [_unperm_rows(torch.mm(dg.t(), xin, **f32), H),
+                    _unperm_rows(torch.mm(dg.t(), Y[l, :-1].reshape(T * B, H), **f32), H), dB, dB]
 
         dX = torch.matmul(dG[0].view(T * B, 4 * H), Wp[0].t()).view(T, B, -1) if need_dx else None
         grads = []

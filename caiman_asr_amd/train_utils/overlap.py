@@ -69,8 +69,10 @@ def _weight_gradient(dy2, x2):
     Both are deterministic: slices / chunks are added in a fixed order."""
     rows = dy2.shape[0]
     S = WGRAD_SPLIT
-    if not dy2.is_cuda or dy2.dtype not in (torch.float16, torch.bfloat16) or rows < 4096 * S:
+    if not dy2.is_cuda or dy2.dtype not in (torch.float16, torch.bfloat16):
         return torch.mm(dy2.t(), x2)
+    if rows < 4096 * S:
+        return torch.mm(dy2.t(), x2, out_dtype=torch.float32)
     if JOINT_WGRAD and dy2.is_contiguous() and x2.is_contiguous() and x2.dtype == dy2.dtype:
         out = _joint_wgrad(dy2, x2)
         if out is not None:
@@ -243,3 +245,44 @@ class _LinearTransposedBackward(torch.autograd.Function):
 
 def linear_transposed_backward(x, weight, bias):
     return _LinearTransposedBackward.apply(x, weight, bias)
+
+
+class _LinearF32Grads(torch.autograd.Function):
+    """torch.nn.Linear under autocast, except that the weight and bias gradients leave the GEMM / the column sum as fp32
+    (autocast's own backward computes them in the 16-bit type and widens afterwards: one more rounding of every element of
+    the parameter gradient, up to 2^-8 of the tensor's range -- the reference does the same,
+    training/caiman_asr_train/rnnt/model.py:409-439 under torch.autocast; here parameter gradients are never rounded).
+    Used for joint_enc / joint_pred; the projection joint_fc has its own function above."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if bias is None:
+            return F.linear(x, weight, bias)
+        # one GEMM with the bias in its epilogue, on the flattened CONTIGUOUS rows: handed a transposed view (the model passes
+        # y.transpose(0, 1)), torch's linear falls back to matmul + a separate bias add -- a second rounding of every output
+        # element in the 16-bit type (29 % of the elements of g one to eleven ulps off, tools/bf16_forward_probe.py)
+        x2 = x.reshape(-1, x.shape[-1])
+        return torch.addmm(bias, x2, weight.t()).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        low = dy2.is_cuda and dy2.dtype in (torch.float16, torch.bfloat16)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, weight.to(dy2.dtype)).view(*dy.shape[:-1], weight.shape[1]).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1]).to(dy2.dtype)
+            dw = (torch.mm(dy2.t(), x2, out_dtype=torch.float32) if low else torch.mm(dy2.t(), x2)).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32 if low else dy2.dtype).to(weight.dtype)
+        return dx, dw, db
+
+
+def linear_f32_grads(x, weight, bias):
+    return _LinearF32Grads.apply(x, weight, bias)

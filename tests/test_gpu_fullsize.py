@@ -159,7 +159,10 @@ def test_base_85m_step_at_128_matches_the_bf16_storage_oracle():
     """BASELINE.json configs[2] per-GPU shape against the ORACLE (not against another kernel of this library): base-85M,
     B = 128, T = 40 frames, one bf16 training step on the weight-resident batch-tile kernels vs oracle.model.loss_and_grads
     rounded where the HIP path stores 16-bit values (`storage=torch.bfloat16`): loss and four gradients, one per
-    sub-network, within 2e-2 of the tensor's range; the unrounded oracle as a loose second check."""
+    sub-network, within 2e-2 of the tensor's range; the unrounded oracle as a loose second check.  (At this size the oracle
+    runs in float32 arithmetic: it is itself one draw of the rounding-flip noise that oracle/bounds.py calibrates on the small
+    models -- two fp32 implementations with the same bf16 rounding points differ by 1-1.5e-2 on the deepest gradient,
+    profiles/r04_bf16_residual.md -- so the flat 2e-2 stays here.)"""
     import json
     import os
 
