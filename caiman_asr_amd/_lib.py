@@ -170,6 +170,7 @@ _SIGS = {
     "caiman_lstm_resident_profile_bwd2": ([P], ctypes.c_int),
     "caiman_lstm_resident_set_failures": ([I32], ctypes.c_int),
     "caiman_lstm_resident_poison": ([P, P, P], ctypes.c_int),
+    "caiman_debug_occupy_cus": ([I32, I32, P], ctypes.c_int),
     "caiman_lstm_resident_launches": ([], ctypes.c_int64),
     "caiman_lstm_resident_would_run": ([I64, I64, I32], ctypes.c_int),
     "caiman_lstm_resident_profile": ([P], ctypes.c_int),

@@ -3438,6 +3438,43 @@ extern "C" int caiman_lstm_resident_poison(float* grad_elem, const uint32_t* see
   return check_launch("caiman_lstm_resident_poison");
 }
 
+namespace caiman { namespace {
+// `workgroups` workgroups that each fill a CU's LDS (so that one lands per CU) and stay for `microseconds` of wall-clock time
+// (s_memrealtime: 100 MHz), then leave.  Bounded by construction: no workgroup waits for another.
+__global__ __launch_bounds__(256) void occupy_cus_kernel(unsigned ticks, unsigned* sink) {
+  extern __shared__ unsigned occupy_lds[];
+  occupy_lds[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned acc = occupy_lds[(threadIdx.x * 7) & 255];
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    acc = acc * 1664525u + 1013904223u;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (acc == 0x9e3779b9u && sink) sink[0] = acc;     // keeps the loop alive; practically never true
+}
+} }  // namespace
+
+// What a collective's kernel does to the chip, without a second rank: `workgroups` CUs are held for `microseconds` on
+// `stream` (RCCL's kernels hold a fixed set of CUs for as long as the slowest rank takes).  The single-GPU rehearsal of
+// "weight-resident LSTM grids and collectives in one job" (tests/test_gpu_distributed.py) queues it on the reducer's
+// communication stream; train_utils/overlap.py::fence_collectives is what keeps the resident grids clear of it.
+extern "C" int caiman_debug_occupy_cus(int workgroups, int microseconds, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(workgroups >= 1 && workgroups <= 256 && microseconds >= 1 && microseconds <= 2000000,
+               "debug_occupy_cus: 1..256 workgroups for 1 us .. 2 s (got %d, %d)", workgroups, microseconds);
+  static bool attr_set = false;
+  const int lds = 96 * 1024;   // more than half of a CU's 160 KB: one such workgroup per CU
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return check_launch("debug_occupy_cus attribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(occupy_cus_kernel, dim3((unsigned)workgroups), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     (unsigned)microseconds * 100u, (unsigned*)nullptr);
+  return check_launch("caiman_debug_occupy_cus");
+}
+
 extern "C" int64_t caiman_lstm_workspace_elems(int64_t B, int64_t H, int backward) {
   if (B < 1 || H < 1) return 0;
   const int64_t bp = (B + 31) / 32 * 32;

@@ -235,6 +235,10 @@ int caiman_lstm_resident_set_failures(int count);
  * caiman_lamb_step's scratch, read as uint32), so that every rank's caiman_lamb_step drops the step.  No-op while
  * no resident launch has been attempted on the device. */
 int caiman_lstm_resident_poison(float* grad_elem, const uint32_t* seen, caiman_stream_t stream);
+/* Test aid (no reference counterpart): hold `workgroups` CUs for `microseconds` on `stream`, as a collective's kernel
+ * would while it waits for the slowest rank.  Lets one GPU rehearse "weight-resident LSTM grids + collectives in one job"
+ * (tests/test_gpu_distributed.py); every workgroup leaves by its own clock. */
+int caiman_debug_occupy_cus(int workgroups, int microseconds, caiman_stream_t stream);
 int64_t caiman_lstm_resident_launches(void);
 /* 1 when a multi-timestep BACKWARD wave call with n_slots slots of hidden size H and batch B would be one resident
  * launch on the current device (mode on, n_slots * H/32 <= CUs, and B <= 32 with H/32 in {2,4,8,16,24,32}, or

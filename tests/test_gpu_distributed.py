@@ -260,9 +260,71 @@ def _nccl_world1_worker(port, out):
         assert host_s < 0.05, f"launching the collectives blocked the host for {host_s * 1e3:.1f} ms"
         assert pending, "the side stream was already idle: the non-blocking check did not see queued work"
         assert fenced and order_ms >= 0.0, (fenced, order_ms)
+        # (4) weight-resident grids and a CU-holding "collective" in ONE job, over several steps (round-3 verdict, next 8):
+        # the first parameter whose gradient is ready in a step (the stack that finishes its backward first) queues a kernel
+        # that holds 32 CUs for 30 ms on the communication stream -- what RCCL's kernel does while it waits for a slow rank.
+        # The other stack's backward (resident launches: every workgroup of a layer must be on the chip together) then has to
+        # start BEHIND it: fence_collectives() is called at the head of every stack's backward; a spy records a main-stream
+        # event right behind each call.  Asserted: every fence that followed the hold completed after the hold's end, no
+        # hand-off timed out, the gradients are those of the run without any of this, and the step paid for the hold.
+        from caiman_asr_amd.rnnt_ext.custom_lstm import encoder_pipe as _ep  # noqa: F401  (the stacks look `overlap` up at call time)
+
+        HOLD_US, fences, holds = 30000, [], []
+        real_fence = overlap.fence_collectives
+
+        def spy_fence():
+            real_fence()
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            fences.append((len(holds), ev))
+
+        def hold_on_first_ready(_param):
+            if holds and holds[-1][0] == step_no[0]:
+                return
+            with torch.cuda.stream(red.comm_stream):
+                _lib.check(lib.caiman_debug_occupy_cus(32, HOLD_US, _lib.stream()))
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(red.comm_stream)
+            holds.append((step_no[0], ev))
+
+        step_no = [0]
+        opt.zero_grad()
+        train_step(m, loss_fn, a1, *batch, None, None, mods)       # the same step without a hold: the gradients to reproduce
+        red.finish()
+        torch.cuda.synchronize()
+        base = {n: p.grad.clone() for n, p in m.named_parameters()}
+        overlap.fence_collectives = spy_fence
+        overlap.register_grad_ready_callback(hold_on_first_ready)
+        try:
+            n_res, step_ms = lib.caiman_lstm_resident_launches(), []
+            for k in range(3):
+                step_no[0] = k
+                opt.zero_grad()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loss_k, nan, _ = train_step(m, loss_fn, a1, *batch, None, None, mods)
+                red.finish()
+                torch.cuda.synchronize()
+                step_ms.append((time.perf_counter() - t0) * 1e3)
+                assert not nan
+                for n, p in m.named_parameters():
+                    err = (p.grad - base[n]).abs().max().item() / (base[n].abs().max().item() + 1e-12)
+                    assert err <= 1e-6, (k, n, err)
+            assert len(holds) == 3, len(holds)
+            assert lib.caiman_lstm_resident_launches() > n_res and lib.caiman_lstm_resident_failures() == 0
+            late = [(h, ev) for h, ev in fences if h >= 1]
+            assert late, "no stack started its backward after a hold was queued: nothing was rehearsed"
+            for h, ev in late:                       # the fence behind hold number h - 1 ended after that hold did
+                assert holds[h - 1][1].elapsed_time(ev) >= 0.0, (h, holds[h - 1][1].elapsed_time(ev))
+            assert min(step_ms) >= HOLD_US / 1e3 * 0.9, step_ms   # the hold is on the critical path: it was waited for
+            exposed = red.exposed_ms()
+        finally:
+            overlap.fence_collectives = real_fence
+            overlap._grad_ready_callbacks.remove(hold_on_first_ready)
         red.remove()
         out.put(("ok", {"worst_grad_err": worst, "host_launch_ms": host_s * 1e3, "buckets": len(red.buckets),
-                        "backend": dist.get_backend()}))
+                        "backend": dist.get_backend(), "hold_step_ms": step_ms, "fences_behind_holds": len(late),
+                        "exposed_ms_with_holds": exposed}))
     except Exception:  # pragma: no cover
         import traceback
 
@@ -282,3 +344,4 @@ def test_rccl_path_runs_in_a_world_of_one_on_the_real_model():
     p.join(timeout=60)
     assert status == "ok", payload
     assert payload["backend"] == "nccl"
+    assert payload["fences_behind_holds"] >= 2 and len(payload["hold_step_ms"]) == 3
