@@ -202,30 +202,60 @@ def launch_ranks(n):
     return proc.returncode if (proc.returncode or result) else 1
 
 
-def decode_record(streams=2000, ticks=100):
+def decode_record(streams=2000, ticks=100, search_runs=4):
     """Second half of BASELINE's metric (configs[4]): streaming beam decode, `streams` concurrent real-time 16 kHz
     streams, beam 4 / temperature 1.4 / <= 8 symbols per frame, from audio.  Runs bench_decode.py as a child process with
     the committed calibration of the synthetic logits (profiles/decode_calibration.json: logit scale and blank bias that
     make seeded random weights emit speech-like token rates; the fit is deterministic, and the record carries the
-    measured token rate so that the workload can be checked)."""
+    measured token rate so that the workload can be checked).  Then MEASURES the capacity: `search_runs` more child runs at
+    other stream counts (a bracketing search that starts from the linear extrapolation of the 2 000-stream tick) and
+    reports the largest count whose p99 tick stayed under the 60 ms of audio it consumes."""
     cal = json.load(open(os.path.join(ROOT, "profiles", "decode_calibration.json")))
-    cmd = [sys.executable, os.path.join(ROOT, "bench_decode.py"), "--decoder", "beam", "--streams", str(streams), "--ticks",
-           str(ticks), "--warmup", "10", "--from-audio", "--scale", repr(cal["logit_scale"]), "--blank-bias",
-           repr(cal["blank_bias"])]
+
+    def run(n, n_ticks):
+        cmd = [sys.executable, os.path.join(ROOT, "bench_decode.py"), "--decoder", "beam", "--streams", str(n), "--ticks",
+               str(n_ticks), "--warmup", "10", "--from-audio", "--scale", repr(cal["logit_scale"]), "--blank-bias",
+               repr(cal["blank_bias"])]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.lstrip().startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return None, (proc.stderr or "no output")[-400:]
+        return json.loads(lines[-1]), None
+
     t0 = time.perf_counter()
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.lstrip().startswith("{")]
-    if proc.returncode != 0 or not lines:
-        return {"error": (proc.stderr or "no output")[-400:]}
-    d = json.loads(lines[-1])
-    return {"metric": d["metric"], "streams": d["streams"], "real_time": d["real_time"], "tick_audio_ms": d["tick_audio_ms"],
-            "tick_latency_ms": d["tick_latency_ms"], "ticks": d["ticks"], "ticks_over_60ms": d["ticks_over_60ms"],
-            "max_streams_at_p99_linear_estimate": d["max_streams_at_p99_linear_estimate"],
-            "tokens_per_encoder_frame": d["tokens_per_encoder_frame"], "beam_width": d["beam_width"],
-            "temperature": d["temperature"], "max_symbols_per_step": d["max_symbols_per_step"], "input": d["input"],
-            "max_stream_lag_frames": d["max_stream_lag_frames"], "frames_settled_by_cap_frac": d["frames_settled_by_cap_frac"],
-            "calibration": "profiles/decode_calibration.json (logit scale / blank bias of the synthetic weights)",
-            "wall_s_including_model_setup": time.perf_counter() - t0}
+    d, err = run(streams, ticks)
+    if d is None:
+        return {"error": err}
+    rec = {"metric": d["metric"], "streams": d["streams"], "real_time": d["real_time"], "tick_audio_ms": d["tick_audio_ms"],
+           "tick_latency_ms": d["tick_latency_ms"], "ticks": d["ticks"], "ticks_over_60ms": d["ticks_over_60ms"],
+           "tokens_per_encoder_frame": d["tokens_per_encoder_frame"], "beam_width": d["beam_width"],
+           "temperature": d["temperature"], "max_symbols_per_step": d["max_symbols_per_step"], "input": d["input"],
+           "max_stream_lag_frames": d["max_stream_lag_frames"], "frames_settled_by_cap_frac": d["frames_settled_by_cap_frac"],
+           "calibration": "profiles/decode_calibration.json (logit scale / blank bias of the synthetic weights)"}
+    # capacity: largest stream count measured real-time (p99 tick < 60 ms), smallest measured not real-time
+    ok_n, ok_p99 = (streams, d["tick_latency_ms"]["p99"]) if d["real_time"] else (0, None)
+    bad_n = None if d["real_time"] else streams
+    tried = [{"streams": streams, "p99_ms": round(d["tick_latency_ms"]["p99"], 2), "real_time": d["real_time"]}]
+    n = int(d["max_streams_at_p99_linear_estimate"] * 2 // 1000 * 1000) if d["real_time"] else streams // 2
+    for _ in range(search_runs):
+        if n <= ok_n or (bad_n is not None and n >= bad_n) or n < 100:
+            break
+        dn, err = run(n, 40)
+        if dn is None:
+            tried.append({"streams": n, "error": err[-120:]})
+            bad_n = n
+        else:
+            tried.append({"streams": n, "p99_ms": round(dn["tick_latency_ms"]["p99"], 2), "real_time": dn["real_time"]})
+            if dn["real_time"]:
+                ok_n, ok_p99 = n, dn["tick_latency_ms"]["p99"]
+            else:
+                bad_n = n
+        n = int((ok_n + bad_n) / 2 // 500 * 500) if bad_n is not None else int(ok_n * 1.5 // 1000 * 1000)
+    rec["max_streams_measured"] = {"real_time_at": ok_n, "p99_ms_there": None if ok_p99 is None else round(ok_p99, 2),
+                                   "not_real_time_at": bad_n, "runs": tried,
+                                   "criterion": "p99 of the 60 ms tick (frontend + encoder + beam search of every stream) < 60 ms"}
+    rec["wall_s_including_model_setup"] = time.perf_counter() - t0
+    return rec
 
 
 def feed_beside_step(step, args, dev, first_index):
