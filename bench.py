@@ -340,6 +340,10 @@ def main():
     ap.add_argument("--features-resident", action="store_true",
                     help="start the timed step from log-mel features resident in HBM (rounds 1-3) instead of resident 16 kHz PCM: "
                          "leaves caiman_logmel_forward + caiman_mel_normalize out of the clock (A/B)")
+    ap.add_argument("--launch-sources", type=int, default=0, metavar="N",
+                    help="after the timed loop, run N more steps under torch.profiler (with Python stacks) and write, per kernel "
+                         "name and calling source line of this repo, launches and device time per step to stderr: where the "
+                         "step's small torch kernels come from")
     ap.add_argument("--feed", action="store_true",
                     help="after the timed loop, time the same steps again WHILE the data feed (AudioBatchLoader: 8 FLAC decode "
                          "threads, side-stream log-mel / normalise / splice kernels) produces one batch per step (N = 1 only)")
@@ -686,6 +690,36 @@ def main():
         native = _lib.lib()
         out["lstm_resident"] = {"launches": int(native.caiman_lstm_resident_launches()),
                                 "handoff_timeouts": int(native.caiman_lstm_resident_failures())}   # must be 0
+        if world == 1 and args.launch_sources > 0:
+            from torch.profiler import ProfilerActivity, profile
+
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+                for i in range(args.launch_sources):
+                    step(args.warmup + i, args.warmup + i)
+                torch.cuda.synchronize()
+            # device kernels carry no stack: attribute each to the CPU op that launched it (linked by correlation id), and that op
+            # to the innermost frame of this repository on its stack
+            agg = {}
+            evs = prof.events()
+            by_corr = {}
+            for e in evs:
+                if e.device_type.name == "CPU" and e.stack:
+                    for k in e.kernels:
+                        by_corr[id(k)] = e
+            for e in evs:
+                if e.device_type.name == "CPU" and e.kernels:
+                    src = next((f for f in e.stack if ("caiman_asr_amd" in f or "bench.py" in f) and "_lib.py" not in f), "?")
+                    src = src.split("caiman-asr/")[-1].split("repo/")[-1]
+                    for k in e.kernels:
+                        key = (k.name[:70], src[:110])
+                        a = agg.setdefault(key, [0, 0.0])
+                        a[0] += 1
+                        a[1] += k.duration
+            rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+            n = args.launch_sources
+            print(f"[launch sources] {sum(v[0] for _, v in rows) / n:.0f} attributed launches per step", file=sys.stderr)
+            for (kn, src), (cnt, us) in rows[:90]:
+                print(f"[launch sources] {us / n:8.1f} us {cnt / n:6.1f} x  {kn:70s} {src}", file=sys.stderr)
         if world == 1 and args.feed:
             try:
                 log("feed beside the step")

@@ -24,6 +24,7 @@
 // HBM once.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "common.h"
@@ -64,6 +65,8 @@ __device__ __forceinline__ f16x4 tr_read(const f16_t* stage, unsigned byte) {
 constexpr int WBN = 256, WBK = 256, WBM = 32, WNW = 8;   // tile: 256 n x 256 k, 32 rows of m per stage
 constexpr int WTN = 8, WTK = 4;                            // 16 x 16 blocks of a wave tile: 128 n, 64 k
 constexpr int WROW = 256;                                  // elements per LDS row of a stage (both operands)
+template <int V>
+using IC8 = std::integral_constant<int, V>;
 
 template <typename T>
 __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __restrict__ dY, const T* __restrict__ Hm,
@@ -230,6 +233,212 @@ __global__ __launch_bounds__(64 * WNW, 1) void joint_wgrad_kernel(const T* __res
       for (int e = 0; e < 4; ++e) out[(int64_t)(a * 16 + kq * 4 + e) * K + b * 16 + li] = acc[a][b][e];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same product on the 8-phase main loop of csrc/joint_gemm.hip (the two waves of a SIMD in opposite roles: one
+// multiplies 16 MFMAs while its partner reads fragments and issues LDS-DMA, then they swap; waves 4-7 run one barrier behind).
+// The reduction over m advances in tiles of 64 rows = four phases (one 64 n x 32 k quadrant of the wave's 128 x 64 tile each);
+// a tile is staged as four units of 16 KB -- [64 rows of m][128 columns], 256-byte rows:
+//   type 0  dY columns {wr * 128 + 0 .. 63}    type 3  dY columns {wr * 128 + 64 .. 127}
+//   type 1  h  columns {wc * 64 + 0 .. 31}     type 2  h  columns {wc * 64 + 32 .. 63}
+// unit u = 4 * tile + type issued at phase u - 6, vmcnt(8) behind every phase's issue, read one phase after the wait that
+// retires it (joint_gemm.hip has the hazard analysis).  Fragments by ds_read_b64_tr_b16 as above; a row's eight 32-byte granules
+// are stored at g ^ x(row), x = (row & 3) | (((row >> 3) & 1) << 2): the eight rows a 32-lane half touches (r .. r + 3 and
+// r + 8 .. r + 11) then cover all eight granules of the 256-byte bank window.  Operands arrive by BUFFER LDS-DMA (descriptor +
+// scalar row offset + per-lane 32-bit offset: no vector address arithmetic in the loop).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void joint_wgrad8_kernel(const T* __restrict__ dY, const T* __restrict__ Hm,
+                                                              float* __restrict__ slabs, int N, int K, int rows_per_slice,
+                                                              int tiles_k, int n_tiles, int slices, int64_t stride_y,
+                                                              int64_t stride_h, int split, const T* __restrict__ dY2,
+                                                              int64_t stride_y2, const T* __restrict__ Hm2, int64_t stride_h2) {
+  using frag = typename wfrag<T>::type;
+  constexpr int UE = 64 * 128;
+  __shared__ __attribute__((aligned(1024))) T u00[UE], u01[UE], u02[UE], u03[UE], u10[UE], u11[UE], u12[UE], u13[UE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+  int t;
+  {
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pslice = t / n_tiles, tt = t - pslice * n_tiles;
+  const int prob = pslice / slices, slice = pslice - prob * slices;
+  const int n0 = (tt / tiles_k) * WBN, k0 = (tt % tiles_k) * WBK;
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
+  if (prob < split) {
+    dY += (int64_t)prob * stride_y;
+    Hm += (int64_t)prob * stride_h;
+  } else {
+    dY = dY2 + (int64_t)(prob - split) * stride_y2;
+    Hm = Hm2 + (int64_t)(prob - split) * stride_h2;
+  }
+  const int wr = wave >> 2, wc = wave & 3;
+  const int kq = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+
+  // DMA: instruction i of wave w fills unit rows (2 w + i) * 4 .. + 3; lane l the 16-byte piece at (row l >> 4, position l & 15)
+  unsigned srcy[2], srch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 4 + (lane >> 4), p = lane & 15;
+    const int x = (r & 3) | (((r >> 3) & 1) << 2);
+    const int cu = (((p >> 1) ^ x) << 4) | ((p & 1) << 3);       // unit column of the piece that belongs at this position
+    srcy[i] = (unsigned)((r * N + (cu >> 6) * 128 + (cu & 63)) * (int)sizeof(T));
+    srch[i] = (unsigned)((r * K + (cu >> 5) * 64 + (cu & 31)) * (int)sizeof(T));
+  }
+  auto rsrc = [&](const T* base) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint64_t u = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
+                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(u), 0, -1, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ry = rsrc(dY + m_begin * N + n0), rh = rsrc(Hm + m_begin * K + k0);
+  const unsigned ystep = (unsigned)(64 * N * (int)sizeof(T)), hstep = (unsigned)(64 * K * (int)sizeof(T));   // one tile of m
+  unsigned yb = 0, hb = 0;        // byte offsets of the first tile of the pair being multiplied
+
+#define CAIMAN_WUNIT(PAR, TY) \
+  ((PAR) == 0 ? ((TY) == 0 ? u00 : (TY) == 1 ? u01 : (TY) == 2 ? u02 : u03) : ((TY) == 0 ? u10 : (TY) == 1 ? u11 : (TY) == 2 ? u12 : u13))
+  auto issue = [&](auto PAR_, auto TY_, unsigned yoff, unsigned hoff) {
+    constexpr int PAR = decltype(PAR_)::value, TY = decltype(TY_)::value;
+    T* dst = CAIMAN_WUNIT(PAR, TY);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      auto lds = (__attribute__((address_space(3))) void*)(dst + (wave * 2 + i) * 4 * 128);
+      if constexpr (TY == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, lds, 16, (int)srcy[i], (int)yoff, 0, 0);
+      if constexpr (TY == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, lds, 16, (int)srcy[i], (int)(yoff + 64 * sizeof(T)), 0, 0);
+      if constexpr (TY == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, lds, 16, (int)srch[i], (int)hoff, 0, 0);
+      if constexpr (TY == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, lds, 16, (int)srch[i], (int)(hoff + 32 * sizeof(T)), 0, 0);
+    }
+  };
+
+  // transposed-read addresses (bytes in a unit), m-step 0; m-step 1 is 32 rows = 8192 bytes further on
+  unsigned adA[4][2], adB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * kq + 4 * h + q4;
+    const int x = (row & 3) | (((row >> 3) & 1) << 2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) adA[a][h] = (unsigned)(row * 256 + (((wr * 4 + a) ^ x) << 5) + p4 * 8);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) adB[b][h] = (unsigned)(row * 256 + (((wc * 2 + b) ^ x) << 5) + p4 * 8);
+  }
+  f32x4 acc[2][4][2][2];     // [nh][a][kh][b]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[i][a][j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  frag af[4][2], bf[2][2][2];   // [a][ms], [kh][b][ms]
+  auto read_frag = [&](const T* unit, unsigned a0, unsigned a1, int ms, frag& f) {
+    const auto lo = tr_read(unit, a0 + (unsigned)(ms * 8192));
+    const auto hi = tr_read(unit, a1 + (unsigned)(ms * 8192));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+  };
+
+  auto phase = [&](auto PAR_, auto PH_, auto SRC_, auto VM_) {
+    constexpr int PAR = decltype(PAR_)::value, PH = decltype(PH_)::value, SRC = decltype(SRC_)::value, VM = decltype(VM_)::value;
+    if constexpr (PH == 0) {
+      const T* ub = CAIMAN_WUNIT(PAR, 1);
+      const T* ua = CAIMAN_WUNIT(PAR, 0);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) read_frag(ub, adB[b][0], adB[b][1], ms, bf[0][b][ms]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) read_frag(ua, adA[a][0], adA[a][1], ms, af[a][ms]);
+    } else if constexpr (PH == 1) {
+      const T* ub = CAIMAN_WUNIT(PAR, 2);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) read_frag(ub, adB[b][0], adB[b][1], ms, bf[1][b][ms]);
+    } else if constexpr (PH == 2) {
+      const T* ua = CAIMAN_WUNIT(PAR, 3);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) read_frag(ua, adA[a][0], adA[a][1], ms, af[a][ms]);
+    }
+    if constexpr (SRC != 0) {
+      constexpr int DP = PH < 2 ? PAR ^ 1 : PAR, TY = (PH + 2) & 3, AHEAD = PAR + (PH < 2 ? 1 : 2);
+      issue(IC8<DP>{}, IC8<TY>{}, yb + AHEAD * ystep, hb + AHEAD * hstep);
+    }
+    if constexpr (VM >= 0) __builtin_amdgcn_s_waitcnt(0x0F70 | VM);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int nh = PH >> 1, kh = (PH == 1 || PH == 2) ? 1 : 0;       // quadrants (0,0) (0,1) (1,1) (1,0)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[nh][a][kh][b] = wmfma(af[a][ms], bf[kh][b][ms], acc[nh][a][kh][b]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = IC8<0>; using I1 = IC8<1>; using I2 = IC8<2>; using I3 = IC8<3>;
+  using VN = IC8<-1>; using V8 = IC8<8>;
+
+  const int nk = rows_per_slice / 64;     // even, at least four
+  issue(I0{}, I0{}, 0u, 0u);
+  issue(I0{}, I1{}, 0u, 0u);
+  issue(I0{}, I2{}, 0u, 0u);
+  issue(I0{}, I3{}, 0u, 0u);
+  issue(I1{}, I0{}, ystep, hstep);
+  issue(I1{}, I1{}, ystep, hstep);
+  __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8): units 0, 1 have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind from here on
+  for (int kt = 0; kt < nk - 2; kt += 2) {
+    phase(I0{}, I0{}, I1{}, V8{});
+    phase(I0{}, I1{}, I1{}, V8{});
+    phase(I0{}, I2{}, I1{}, V8{});
+    phase(I0{}, I3{}, I1{}, V8{});
+    phase(I1{}, I0{}, I1{}, V8{});
+    phase(I1{}, I1{}, I1{}, V8{});
+    phase(I1{}, I2{}, I1{}, V8{});
+    phase(I1{}, I3{}, I1{}, V8{});
+    yb += 2 * ystep;
+    hb += 2 * hstep;
+  }
+  phase(I0{}, I0{}, I1{}, V8{});
+  phase(I0{}, I1{}, I1{}, V8{});
+  phase(I0{}, I2{}, I0{}, IC8<6>{});
+  phase(I0{}, I3{}, I0{}, IC8<4>{});
+  phase(I1{}, I0{}, I0{}, IC8<2>{});
+  phase(I1{}, I1{}, I0{}, IC8<0>{});
+  phase(I1{}, I2{}, I0{}, VN{});
+  phase(I1{}, I3{}, I0{}, VN{});
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef CAIMAN_WUNIT
+
+  // epilogue: D[i][j] of a block sits in lane (j = lane & 15, i = 4 (lane >> 4) + reg): rows = n (A operand), columns = k
+  float* out = slabs + ((int64_t)pslice * N + n0 + wr * 128) * K + k0 + wc * 64;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            out[(int64_t)(nh * 64 + a * 16 + kq * 4 + e) * K + kh * 32 + b * 16 + li] = acc[nh][a][kh][b][e];
+}
+
 }  // namespace
 }  // namespace caiman
 
@@ -243,25 +452,26 @@ namespace {
 // 8704 x 768 (joint): 102 tiles -> 5 slices (510 workgroups, 2 rounds); 17408 x 1024: 272 tiles -> 16 slices (17 rounds; one slice
 // would leave the second round 6 % full); six LSTM layers of 4096 x 1024 at 8 900 rows: 384 tiles -> 2 slices (3 rounds).
 int wgrad_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* rows_per_slice, double* seconds) {
-  if (!(dtype == CAIMAN_BF16 || dtype == CAIMAN_F16) || N < 256 || N % 256 || K < 256 || K % 256 || M < 128 || batch < 1)
+  if (!(dtype == CAIMAN_BF16 || dtype == CAIMAN_F16) || N < 256 || N % 256 || K < 256 || K % 256 || M < 256 || batch < 1)
     return 0;
   if (N * 2 * 32 >= ((int64_t)1 << 31) || M * N >= ((int64_t)1 << 46)) return 0;
   const int64_t tiles = (N / 256) * (K / 256) * batch;
   static const int env_s = std::getenv("CAIMAN_WGRAD_SLICES") ? std::atoi(std::getenv("CAIMAN_WGRAD_SLICES")) : 0;
   constexpr int64_t kCus = 256;
+  // (round 4: slices are multiples of 128 rows -- pairs of the 8-phase kernel's 64-row tiles -- and a tile takes 1.35 us)
   auto cost = [&](int64_t c) {
-    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (32 * c), rest = M - c * steps * 32;
-    return (double)rounds * ((double)steps * 0.86e-6 + 17e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
+    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (128 * c) * 2, rest = M - c * steps * 64;
+    return (double)rounds * ((double)steps * 1.35e-6 + 17e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
            (double)(rest * batch) * (double)(N * K) * 2.0 / 0.9e15;
   };
   int64_t s = 1;
   double best = 1e30;
-  for (int64_t c = 1; c <= 32 && M / (32 * c) >= 4; ++c)
+  for (int64_t c = 1; c <= 32 && M / (128 * c) >= 2; ++c)
     if (cost(c) < best) best = cost(c), s = c;
   if (env_s > 0) s = env_s;
-  while (s > 1 && M / (32 * s) < 4) --s;
-  const int64_t per = M / (32 * s) * 32;
-  if (per < 128) return 0;
+  while (s > 1 && M / (128 * s) < 2) --s;
+  const int64_t per = M / (128 * s) * 128;
+  if (per < 256 || per * N * 2 >= ((int64_t)1 << 32) || per * K * 2 >= ((int64_t)1 << 32)) return 0;
   if (rows_per_slice) *rows_per_slice = per;
   if (seconds) *seconds = cost(s);
   return (int)s;
@@ -303,6 +513,21 @@ extern "C" int caiman_wgrad_tn2(const void* dY, int64_t stride_y, const void* H,
   const int64_t grid = (int64_t)n_tiles * slices * (batch + batch2);
   CAIMAN_CHECK(grid < ((int64_t)1 << 31), "wgrad_tn: too many tiles");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // the 8-phase kernel wherever the slices are pairs of its 64-row tiles (what caiman_wgrad_tn_plan hands out);
+  // CAIMAN_WGRAD_KERNEL=ring: the round-3 four-stage ring kernel (A/B)
+  static const bool ring = std::getenv("CAIMAN_WGRAD_KERNEL") != nullptr && std::string(std::getenv("CAIMAN_WGRAD_KERNEL")) == "ring";
+  if (!ring && rows_per_slice % 128 == 0 && rows_per_slice >= 256 && rows_per_slice * N * 2 < ((int64_t)1 << 32) &&
+      rows_per_slice * K * 2 < ((int64_t)1 << 32)) {
+    if (dtype == CAIMAN_BF16)
+      hipLaunchKernelGGL((joint_wgrad8_kernel<bf16_t>), dim3((unsigned)grid), dim3(512), 0, s, (const bf16_t*)dY, (const bf16_t*)H,
+                         slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
+                         (const bf16_t*)dY2, stride_y2, (const bf16_t*)H2, stride_h2);
+    else
+      hipLaunchKernelGGL((joint_wgrad8_kernel<f16_t>), dim3((unsigned)grid), dim3(512), 0, s, (const f16_t*)dY, (const f16_t*)H,
+                         slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
+                         (const f16_t*)dY2, stride_y2, (const f16_t*)H2, stride_h2);
+    return check_launch("transposed-read weight gradient (8-phase)");
+  }
   if (dtype == CAIMAN_BF16)
     hipLaunchKernelGGL((joint_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(64 * WNW), 0, s, (const bf16_t*)dY, (const bf16_t*)H,
                        slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,

@@ -226,8 +226,8 @@ def test_projection_autograd_takes_the_handwritten_weight_gradient_and_agrees_wi
 
 
 @pytest.mark.parametrize("P,M,N,K,pad", [
-    (1, 131, 256, 256, 0),       # four stages and three rows for the library remainder
-    (3, 1000, 512, 256, 64),     # operands a constant stride apart (64 spare rows between them), 1000 = 31 x 32 + 8
+    (1, 259, 256, 256, 0),       # the shortest slice (two pairs of 64-row tiles) and three rows for the library remainder
+    (3, 1000, 512, 256, 64),     # operands a constant stride apart (64 spare rows between them), 1000 = 7 x 128 + 104
     (6, 8896, 4096, 1024, 32),   # six post-encoder LSTM layers at B = 32: dR = dG^T . h_prev
     (5, 2300, 1024, 2048, 0),    # K = 2048 (stacked input)
 ])
@@ -258,7 +258,7 @@ def test_wgrad_tn_declines_what_it_cannot_address():
     assert wgrad_tn(a, torch.zeros(2, 512, 240, device=DEV, dtype=torch.bfloat16)) is None      # K = 240 (layer 0)
     assert wgrad_tn(a.transpose(1, 2), a.transpose(1, 2)) is None                                   # rows not contiguous
     assert wgrad_tn(a.float(), a.float()) is None                                                   # fp32 operands
-    assert wgrad_tn(a[:, :100], a[:, :100]) is None                                                 # fewer than 128 rows
+    assert wgrad_tn(a[:, :200], a[:, :200]) is None                                                 # fewer than 256 rows
 
 
 def test_two_strided_groups_in_one_launch():
@@ -266,7 +266,7 @@ def test_two_strided_groups_in_one_launch():
     products, the same gradients from layer 1 on against the activations from step 1) as ONE launch of 11 products."""
     from caiman_asr_amd.train_utils.overlap import wgrad_tn
 
-    L, T, B, H = 6, 35, 8, 256                      # rows = 280 = 8 x 32 + 24: the library takes the last 24 rows
+    L, T, B, H = 6, 35, 8, 256                      # rows = 280 = 2 x 128 + 24: the library takes the last 24 rows
     g = torch.Generator(device=DEV).manual_seed(17)
     dG = torch.randn(L, T * B, 4 * H, device=DEV, generator=g).to(torch.bfloat16)
     Y = torch.randn(L, T + 1, B, H, device=DEV, generator=g).to(torch.bfloat16)
