@@ -25,8 +25,20 @@ class RNNTState:
     pred_net_state: PredNetState
 
 
+class BatchChunks:
+    """All hidden states of an LSTM stack, kept as one (h, c) pair [L, T, b, H] per chunk of the batch (rnnt/model.py runs the
+    layer pipeline 32 utterances at a time where the weight-resident kernels only exist for up to 32): the selections below
+    gather from each chunk and concatenate the small results, instead of concatenating gigabytes of states first."""
+
+    def __init__(self, parts, bounds):
+        self.parts, self.bounds = list(parts), list(bounds)
+
+
 def get_last_nonpadded_states(all_hid, lens, how_far_back: int = 0):
     """all_hid: (h, c) each [L, T, B, H]; pick step lens[b]-1-how_far_back per utterance."""
+    if isinstance(all_hid, BatchChunks):
+        got = [get_last_nonpadded_states(part, lens[a:b], how_far_back) for part, (a, b) in zip(all_hid.parts, all_hid.bounds)]
+        return torch.cat([g[0] for g in got], dim=1), torch.cat([g[1] for g in got], dim=1)
     idx = (lens.long() - 1 - how_far_back)
     cols = torch.arange(len(lens), device=idx.device)
     return all_hid[0][:, idx, cols, :], all_hid[1][:, idx, cols, :]
