@@ -39,7 +39,7 @@ import torch.distributed as dist
 FRAME_SECONDS = 0.03  # 10 ms hop x 3 frame subsampling (training/caiman_asr_train/utils/frame_width.py)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
-PMC_FILE = "r04a_base_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
+PMC_FILE = "r04_base_pmc_traffic.json"   # builder-run counter passes of this round (falls back to nothing when absent)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 BASE_RNNT = dict(  # training/configs/base-8703sp.yaml:73-94

@@ -20,7 +20,7 @@ from collections import defaultdict
 
 NAMES = ("lstm_bwd_resident2_bt_dma|lstm_bwd_resident2_bt|lstm_fwd_resident_bt_dma|lstm_fwd_resident_bt|lstm_fwd_resident_dma|lstm_bwd_resident2|lstm_bwd_resident|lstm_fwd_resident|"
          "lstm_bwd_step_mfma|lstm_fwd_step_mfma|loss_bwd_colsum_kernel|loss_row_desc_kernel|loss_bwd_kernel|loss_fwd_kernel|lse_rows_kernel|"
-         "lse_partials_kernel|joint_fc_gemm8_kernel|joint_fc_gemm_kernel|joint_wgrad_kernel|joint_bwd_kernel|joint_fwd_kernel|lamb_stage1|lamb_stage2|gnorm_kernel|beam_topk_reg_kernel|beam_topk_kernel|"
+         "lse_partials_kernel|joint_fc_gemm8_kernel|joint_fc_gemm_kernel|joint_wgrad8_kernel|joint_wgrad_kernel|occupy_cus_kernel|joint_bwd_kernel|joint_fwd_kernel|lamb_stage1|lamb_stage2|gnorm_kernel|beam_topk_reg_kernel|beam_topk_kernel|"
          "lstm_cell_kernel|gather_inputs_kernel|joint_act_kernel|proj_gemm_kernel|lstm_images_kernel|lstm_grad_deliver_kernel|logmel_kernel|"
          "mel_normalize_kernel|specaug_splice_kernel|dbias_rows_kernel")
 
