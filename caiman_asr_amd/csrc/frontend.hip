@@ -52,9 +52,10 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
                                                                         int32_t* __restrict__ out_len) {
   __shared__ float re[kFramesPerBlock][NFFT];
   __shared__ float im[kFramesPerBlock][NFFT];
+  extern __shared__ float sig[];        // the block's padded + dithered samples: (frames - 1) * hop + win_len + 1 of them
   const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
   const int b = blockIdx.y;
-  const int64_t frame = (int64_t)blockIdx.x * kFramesPerBlock + w;
+  const int64_t frame0 = (int64_t)blockIdx.x * kFramesPerBlock, frame = frame0 + w;
   const int64_t n = p.audio_len[b];
   const int64_t total = n + p.pad;  // padded signal length
   const int64_t nframes = total >= p.win_len ? (total - p.win_len) / p.hop + 1 : 0;
@@ -62,20 +63,23 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
   const bool live = frame < nframes;
   const float* x = p.audio + (int64_t)b * p.max_samples;
 
-  auto sample = [&](int64_t q) -> float {  // padded + dithered signal at padded index q (clamped at 0)
+  // ---- the samples the block's frames touch, ONCE (round 4: every frame used to evaluate its 2 x 400 dithered samples --
+  // a counter-based Gaussian each -- itself, 4.2 x the work; values and arithmetic per element are unchanged)
+  const int nsig = (kFramesPerBlock - 1) * p.hop + p.win_len + 1;
+  const int64_t q0 = frame0 * p.hop - 1;                       // sig[i] = padded signal at index q0 + i (clamped at 0)
+  for (int i = threadIdx.x; i < nsig; i += kFramesPerBlock * kWave) {
+    int64_t q = q0 + i;
     if (q < 0) q = 0;                      // PreemphasisFilter border = clamp
     float v = (q >= p.pad && q - p.pad < n) ? x[q - p.pad] : 0.f;
     if (p.dither != 0.f) v += p.dither * gauss_from(p.seed, (uint64_t)b * (uint64_t)(p.max_samples + p.pad) + (uint64_t)q);
-    return v;
-  };
-
+    sig[i] = v;
+  }
+  __syncthreads();
   // ---- window into LDS, bit-reversed -----------------------------------------------------------
+  const float* sw = sig + w * p.hop;       // sw[i + 1] = sample(frame * hop + i), sw[i] = the sample before it
   for (int i = lane; i < NFFT; i += kWave) {
     float v = 0.f;
-    if (live && i < p.win_len) {
-      const int64_t q = frame * p.hop + i;
-      v = (sample(q) - p.preemph * sample(q - 1)) * p.window[i];
-    }
+    if (live && i < p.win_len) v = (sw[i + 1] - p.preemph * sw[i]) * p.window[i];
     const int j = __brev((unsigned)i) >> (32 - p.log2_nfft);
     re[w][j] = v;
     im[w][j] = 0.f;
@@ -110,8 +114,9 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
     if (k <= NFFT / 2) re[w][k] = pw[q];
   }
   __syncthreads();
-  // ---- mel + log ----------------------------------------------------------------------------------
-  if (frame < p.max_frames) {
+  // ---- mel + log: staged per block in im[] as [mel][frame of the block], then written as runs of consecutive frames ------
+  float* stage = &im[0][0];                // 8 x NFFT floats: room for nmel <= NFFT rows of 8
+  {
     const int nb = NFFT / 2 + 1;
     for (int m = lane; m < p.nmel; m += kWave) {
       float acc = 0.f;
@@ -120,8 +125,13 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
         for (int k = p.mel_lo[m]; k < p.mel_hi[m]; ++k) acc += wrow[k] * re[w][k];
         acc = logf(fmaxf(acc, p.log_floor));
       }
-      out[((int64_t)b * p.nmel + m) * p.max_frames + frame] = live ? acc : 0.f;  // Pad: fill 0
+      stage[m * kFramesPerBlock + w] = live ? acc : 0.f;  // Pad: fill 0
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.nmel * kFramesPerBlock; i += kFramesPerBlock * kWave) {
+    const int m = i / kFramesPerBlock, fr = i - m * kFramesPerBlock;
+    if (frame0 + fr < p.max_frames) out[((int64_t)b * p.nmel + m) * p.max_frames + frame0 + fr] = stage[i];
   }
 }
 
@@ -240,9 +250,22 @@ extern "C" int caiman_logmel_forward(const float* audio, const int32_t* audio_le
               win_len, hop, nfft, lg, nmel, initial_pad, preemph, dither, log_floor, seed};
   const dim3 grid((unsigned)((max_frames + kFramesPerBlock - 1) / kFramesPerBlock), (unsigned)B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (nfft == 256) hipLaunchKernelGGL((logmel_kernel<256>), grid, dim3(kFramesPerBlock * kWave), 0, st, p, out, out_len);
-  else if (nfft == 512) hipLaunchKernelGGL((logmel_kernel<512>), grid, dim3(kFramesPerBlock * kWave), 0, st, p, out, out_len);
-  else hipLaunchKernelGGL((logmel_kernel<1024>), grid, dim3(kFramesPerBlock * kWave), 0, st, p, out, out_len);
+  const size_t sig_bytes = (size_t)((kFramesPerBlock - 1) * hop + win_len + 1) * sizeof(float);
+  CAIMAN_CHECK(nmel <= nfft && sig_bytes + (size_t)2 * kFramesPerBlock * nfft * sizeof(float) <= 150 * 1024,
+               "logmel_forward: nmel <= nfft and %d frames of hop %d / window %d must fit the block's sample buffer",
+               kFramesPerBlock, hop, win_len);
+#define CAIMAN_LOGMEL(NF)                                                                                                  \
+  do {                                                                                                                     \
+    auto kern = logmel_kernel<NF>;                                                                                         \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                            (int)sig_bytes) != hipSuccess)                                                                 \
+      return check_launch("logmel_forward attribute");                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(kFramesPerBlock * kWave), sig_bytes, st, p, out, out_len);                         \
+  } while (0)
+  if (nfft == 256) CAIMAN_LOGMEL(256);
+  else if (nfft == 512) CAIMAN_LOGMEL(512);
+  else CAIMAN_LOGMEL(1024);
+#undef CAIMAN_LOGMEL
   return check_launch("caiman_logmel_forward");
 }
 
