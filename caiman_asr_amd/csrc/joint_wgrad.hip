@@ -457,12 +457,18 @@ int wgrad_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* r
   if (N * 2 * 32 >= ((int64_t)1 << 31) || M * N >= ((int64_t)1 << 46)) return 0;
   const int64_t tiles = (N / 256) * (K / 256) * batch;
   static const int env_s = std::getenv("CAIMAN_WGRAD_SLICES") ? std::atoi(std::getenv("CAIMAN_WGRAD_SLICES")) : 0;
-  constexpr int64_t kCus = 256;
-  // (round 4: slices are multiples of 128 rows -- pairs of the 8-phase kernel's 64-row tiles -- and a tile takes 1.35 us)
+  // rounds are counted in workgroups per CU of THIS device (one workgroup per CU: 128 KB of LDS)
+  static const int64_t kCus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return (int64_t)(n > 0 ? n : 256);
+  }();
+  // (round 4: slices are multiples of 128 rows -- pairs of the 8-phase kernel's 64-row tiles; 1.40 us per tile and 35 us per
+  // round of workgroups fitted to tools/wgrad_tn_bench.py: 153 / 443 / 597 / 1391 us measured for 1 x 17 792, 5 and 6 x 8 896, 6 x 35 584 rows)
   auto cost = [&](int64_t c) {
     const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (128 * c) * 2, rest = M - c * steps * 64;
-    return (double)rounds * ((double)steps * 1.35e-6 + 17e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
-           (double)(rest * batch) * (double)(N * K) * 2.0 / 0.9e15;
+    return (double)rounds * ((double)steps * 1.40e-6 + 35e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
+           (rest > 0 ? 15e-6 + (double)(rest * batch) * (double)(N * K) * 2.0 / 0.9e15 : 0.0);
   };
   int64_t s = 1;
   double best = 1e30;

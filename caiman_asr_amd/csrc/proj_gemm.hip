@@ -456,6 +456,9 @@ extern "C" int caiman_lstm_step_gemm(const void* X, int64_t ldx_in, const void* 
   CAIMAN_CHECK(n >= 0 && n <= 0x7fffffffLL && hidden >= 32 && hidden % 32 == 0 && K >= 128 && K % 128 == 0 && ldx_in >= K &&
                    ldx_in % 8 == 0 && ldx >= (h_pool_next ? 2 * hidden : hidden) && 4 * hidden <= 0x7fffffffLL,
                "lstm_step_gemm: bad extents (hidden %% 32, K %% 128, ldx_in %% 8)");
+  // the kernel's per-lane operand offsets are 32-bit byte offsets from the first row
+  CAIMAN_CHECK(n * ldx_in * 2 < ((int64_t)1 << 32) && n * ldx * 2 < ((int64_t)1 << 32),
+               "lstm_step_gemm: %lld rows of %lld elements exceed the kernel's 32-bit row offsets", (long long)n, (long long)ldx_in);
   if (n == 0) return CAIMAN_OK;
   CAIMAN_CHECK(X && W && bias && c_pool_l && h_pool_l && slot_in && slot_out && X_next, "lstm_step_gemm: null pointer");
   auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };

@@ -74,8 +74,12 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(const T* __restrict__ x,
   const int32_t* lab = p.label + (int64_t)b * (p.max_glen - 1);
   const int64_t off = p.packed ? (b == 0 ? 0 : p.batch_offset[b - 1]) : (int64_t)b * p.max_flen * p.max_glen;
   const int64_t stride = p.packed ? Un : p.max_glen;
-  const T* xb = x + off * p.V;
-  const A* db = denom + off;
+  // An utterance without cells (f_len == 0) owns no block of the packed buffers: its lanes are all inactive, but the
+  // prefetch ring below loads "cell 0 of the utterance" unconditionally -- point it at cell 0 of the whole buffer, which
+  // always exists (the last utterance of a packed batch would otherwise read past the logits and the denominators).
+  const bool has_cells = Tn > 0 && Un > 0;
+  const T* xb = has_cells ? x + off * p.V : x;
+  const A* db = has_cells ? denom + off : denom;
   const A dp_lam = (A)p.dp_lam, eos_lam = (A)p.eos_lam, star_lam = (A)p.star_lam;
   const A Tf = (A)Tn;
 
