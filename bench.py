@@ -679,6 +679,20 @@ def main():
                                                         "same_launch_population": pmc[kname].get("same_population")}
                 except Exception:
                     pass
+            # the three products of the joint projection (hand-written MFMA GEMMs, csrc/joint_gemm.hip / joint_wgrad.hip: the
+            # largest kernels of the step by time): 2 M N K FLOP each over the live event-to-event time of their launches
+            # (forward: GEMM + LSE epilogue + the partials reduction; weight gradient: kernel + slab sum + remainder rows)
+            jg = {k: summ[k] for k in ("joint_gemm_fwd", "joint_gemm_dx", "joint_gemm_dw") if k in summ}
+            if jg:
+                flop, ms = sum(v[3] for v in jg.values()), sum(v[1] for v in jg.values())
+                out["roofline_joint_gemm"] = {
+                    "kernel": "joint_fc_gemm8_kernel (forward + row LSE, input gradient) + joint_wgrad8_kernel (weight gradient)",
+                    "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flop / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "per_product": {k[11:]: {"ms_per_step": v[1] / args.steps, "tflops": v[3] / (v[1] * 1e-3) / 1e12}
+                                    for k, v in jg.items()},
+                    "note": "live HIP events around each call; rocprofv3 counterparts in profiles/r04_base_summary.md "
+                            "(64.5 % / 69.3 % SQ_VALU_MFMA_BUSY)"}
             if "loss_bwd" in summ:
                 n_launch, ms = summ["loss_bwd"][0], summ["loss_bwd"][1]
                 alg = cells * N_CLASSES * 2 * 2  # V*s read + V*s write per lattice cell

@@ -112,9 +112,11 @@ def _joint_gemm(a2, w, bias, want_lse):
     if want_lse:
         lse = torch.empty((M,), dtype=torch.float32, device=a2.device)
         ws = torch.empty((lib.caiman_joint_fc_workspace_elems(M, N),), dtype=torch.float32, device=a2.device)
-    _lib.check(lib.caiman_joint_fc_forward(_lib.ptr(a2), _lib.ptr(w), None if bias is None else _lib.ptr(bias), _lib.ptr(c),
-                                           None if lse is None else _lib.ptr(lse), None if ws is None else _lib.ptr(ws),
-                                           M, N, K, tag, _lib.stream()))
+    # `nbytes` of the bracket carries the product's FLOP count (bench.py prices these kernels against the MFMA peak)
+    with _lib.timed("joint_gemm_fwd" if want_lse else "joint_gemm_dx", 1, 2 * M * N * K):
+        _lib.check(lib.caiman_joint_fc_forward(_lib.ptr(a2), _lib.ptr(w), None if bias is None else _lib.ptr(bias), _lib.ptr(c),
+                                               None if lse is None else _lib.ptr(lse), None if ws is None else _lib.ptr(ws),
+                                               M, N, K, tag, _lib.stream()))
     return c, lse
 
 
@@ -194,7 +196,10 @@ def _joint_wgrad(dy2, x2):
     """The joint projection's instance: dy2 [M, N]^T . x2 [M, K] -> [N, K] fp32, or None (shape outside the kernel)."""
     if dy2.shape[0] < 512:
         return None
-    out = wgrad_tn(dy2.unsqueeze(0), x2.unsqueeze(0))
+    from caiman_asr_amd import _lib
+
+    with _lib.timed("joint_gemm_dw", 1, 2 * dy2.shape[0] * dy2.shape[1] * x2.shape[1]):
+        out = wgrad_tn(dy2.unsqueeze(0), x2.unsqueeze(0))
     return None if out is None else out[0]
 
 
