@@ -245,12 +245,19 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
   panels pc, pn;                                         // descriptors of the tile's A / W panels, and the next tile's
   int kb = 0;                                            // byte offset (in a row) of the K tile pair being multiplied
   frag af[4][2], wf[2][2][2];
+#ifdef JG_NO_READS
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "=v"((&af[0][0])[i]), "=v"((&wf[0][0][0])[i]));   // defined, opaque
+#endif
 
   // one phase.  PAR: parity of the K tile being multiplied; PH: phase 0..3; SRC: 0 nothing to issue, 1 unit (phase + 6) of
   // this tile, 2 the unit of the NEXT tile that takes its place; VM: the counted wait behind it (-1: none)
   auto phase = [&](auto PAR_, auto PH_, auto SRC_, auto VM_) {
     constexpr int PAR = decltype(PAR_)::value, PH = decltype(PH_)::value, SRC = decltype(SRC_)::value, VM = decltype(VM_)::value;
-    // ---- load part
+    // ---- load part (JG_NO_READS / JG_NO_DMA: measurement builds that leave one of its two halves out -- results invalid;
+    // tools/jgemm_ablate.py: input-gradient instance 2.80-2.93 ms shipped, 2.38 without the reads, 2.21 without the DMA issue,
+    // MFMA floor 1.63 at 2.4 GHz.  Issuing each phase's second DMA instruction behind its MFMAs instead: 2.87 vs 2.80, slower)
+#ifndef JG_NO_READS
     if constexpr (PH == 0) {
       const T* ua = CAIMAN_UNIT(PAR, 0);
       const T* uw = CAIMAN_UNIT(PAR, 1);
@@ -276,7 +283,12 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) af[b][ks] = *reinterpret_cast<const frag*>(ua + abase[ks] + b * 16 * 64);
     }
+#endif
+#ifdef JG_NO_DMA
+    if constexpr (false) {
+#else
     if constexpr (SRC != 0) {
+#endif
       // unit phase + 6: phases 0, 1 fill types 2, 3 of the other parity (the next K tile), phases 2, 3 types 0, 1 of this
       // parity (the K tile after that).  kb is the row offset of the FIRST K tile of the pair being multiplied (parity 0).
       constexpr int DP = PH < 2 ? PAR ^ 1 : PAR, TY = (PH + 2) & 3;
