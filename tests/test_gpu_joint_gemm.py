@@ -251,6 +251,30 @@ def test_batched_weight_gradients_match_fp64_products(P, M, N, K, pad):
         assert (dw[p][:, 7] == 0).all()
 
 
+def test_weight_gradient_kernel_is_deterministic_over_repeated_launches():
+    """Race screen for the 8-phase weight-gradient kernel (a transposed read placed before the wait + barrier that retire its
+    unit's DMA passes a reference check whenever the DMA happens to land first): the joint projection's product at a quarter of
+    the training size, 10 launches, bit-identical results with a second stream varying the timing; checked once against fp64."""
+    from caiman_asr_amd.train_utils.overlap import _joint_wgrad
+
+    M, N, K = 76000, 8704, 768
+    g = torch.Generator(device=DEV).manual_seed(23)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    d0 = _joint_wgrad(dy, x)
+    assert d0 is not None and d0.dtype == torch.float32
+    ref = dy[:, :512].double().t() @ x.double()
+    assert (d0[:512].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    for i in range(10):
+        if i % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    a @ a
+        assert torch.equal(_joint_wgrad(dy, x), d0), i
+
+
 def test_wgrad_tn_declines_what_it_cannot_address():
     from caiman_asr_amd.train_utils.overlap import wgrad_tn
 
