@@ -179,12 +179,12 @@ def test_step_at_128_per_gpu_matches_the_bf16_storage_oracle(size, V):
     lib = _lib.lib()
     cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"rnnt_cfg_{size}.json")))
     cfg = dict(cfg, enc_dropout=0.0, pred_dropout=0.0, joint_dropout=0.0)
-    B, T1 = 128, 40
+    B, T1 = 128, (40 if size == "base" else 24)      # (large: 24 frames keep the CPU oracle of the 196 M model near a minute)
     torch.manual_seed(5)
     m = RNNT(n_classes=V, **cfg).to(DEV).train()
     sd = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
     rng = np.random.default_rng(2)
-    x_lens = rng.integers(24, T1 + 1, size=B)
+    x_lens = rng.integers(min(24, T1 - 8), T1 + 1, size=B)
     x_lens[0] = T1
     y_lens = rng.integers(1, 4, size=B)
     x = rng.standard_normal((T1, B, 240)).astype(np.float32)
