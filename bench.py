@@ -707,33 +707,26 @@ def main():
         if world == 1 and args.launch_sources > 0:
             from torch.profiler import ProfilerActivity, profile
 
-            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                         experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
                 for i in range(args.launch_sources):
                     step(args.warmup + i, args.warmup + i)
                 torch.cuda.synchronize()
-            # device kernels carry no stack: attribute each to the CPU op that launched it (linked by correlation id), and that op
-            # to the innermost frame of this repository on its stack
-            agg = {}
-            evs = prof.events()
-            by_corr = {}
-            for e in evs:
-                if e.device_type.name == "CPU" and e.stack:
-                    for k in e.kernels:
-                        by_corr[id(k)] = e
-            for e in evs:
-                if e.device_type.name == "CPU" and e.kernels:
-                    src = next((f for f in e.stack if ("caiman_asr_amd" in f or "bench.py" in f) and "_lib.py" not in f), "?")
-                    src = src.split("caiman-asr/")[-1].split("repo/")[-1]
-                    for k in e.kernels:
-                        key = (k.name[:70], src[:110])
-                        a = agg.setdefault(key, [0, 0.0])
-                        a[0] += 1
-                        a[1] += k.duration
+            # torch operators grouped by their Python call stack: launches and device time per step of every (operator, innermost
+            # frame of this repository) pair
+            n, agg = args.launch_sources, {}
+            for e in prof.key_averages(group_by_stack_n=12):
+                dev_us = getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)
+                if dev_us <= 0 or not e.key.startswith("aten::"):
+                    continue
+                src = next((f for f in e.stack if ("caiman_asr_amd" in f or "bench.py" in f) and "_lib.py" not in f), "?")
+                src = src.split("caiman-asr/")[-1].split("repo/")[-1]
+                a = agg.setdefault((e.key, src[:120]), [0, 0.0])
+                a[0] += e.count
+                a[1] += e.self_device_time_total if hasattr(e, "self_device_time_total") else dev_us
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-            n = args.launch_sources
-            print(f"[launch sources] {sum(v[0] for _, v in rows) / n:.0f} attributed launches per step", file=sys.stderr)
-            for (kn, src), (cnt, us) in rows[:90]:
-                print(f"[launch sources] {us / n:8.1f} us {cnt / n:6.1f} x  {kn:70s} {src}", file=sys.stderr)
+            for (op, src), (cnt, us) in rows[:70]:
+                print(f"[launch sources] {us / n:8.1f} us {cnt / n:6.1f} x  {op:34s} {src}", file=sys.stderr)
         if world == 1 and args.feed:
             try:
                 log("feed beside the step")

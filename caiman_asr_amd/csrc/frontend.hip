@@ -17,6 +17,7 @@ namespace caiman {
 namespace {
 
 constexpr int kFramesPerBlock = 8;
+constexpr int kMelRun = 32;     // weights per mel filter kept in LDS (a triangular filter of the 80-band bank spans <= 24 bins of a 512-point FFT)
 
 __device__ __forceinline__ float gauss_from(uint64_t seed, uint64_t idx) {
   // counter-based N(0,1): two splitmix64 uniforms -> Box-Muller
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
                                                                         int32_t* __restrict__ out_len) {
   __shared__ float re[kFramesPerBlock][NFFT];
   __shared__ float im[kFramesPerBlock][NFFT];
-  extern __shared__ float sig[];        // the block's padded + dithered samples: (frames - 1) * hop + win_len + 1 of them
+  extern __shared__ float sig[];        // the block's padded + dithered samples: (frames - 1) * hop + win_len + 1 of them,
+  //                                       then the tables every wave walks: twiddles, window, the filters' non-zero runs
   const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
   const int b = blockIdx.y;
   const int64_t frame0 = (int64_t)blockIdx.x * kFramesPerBlock, frame = frame0 + w;
@@ -66,6 +68,22 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
   // ---- the samples the block's frames touch, ONCE (round 4: every frame used to evaluate its 2 x 400 dithered samples --
   // a counter-based Gaussian each -- itself, 4.2 x the work; values and arithmetic per element are unchanged)
   const int nsig = (kFramesPerBlock - 1) * p.hop + p.win_len + 1;
+  // tables in LDS (round 4: the radix-2 stages fetched two twiddles per butterfly and the filters one weight per bin from
+  // GLOBAL memory inside dependent loops -- 12 us per frame-wave for 50 kFLOP): cos / sin [NFFT / 2], window [win_len],
+  // and per filter the first kMelRun weights of its non-zero run (longer runs read the rest from global memory)
+  float* twc = sig + ((nsig + 3) & ~3);
+  float* tws = twc + NFFT / 2;
+  float* win = tws + NFFT / 2;
+  float* melw = win + ((p.win_len + 3) & ~3);                 // [nmel][kMelRun]
+  for (int i = threadIdx.x; i < NFFT / 2; i += kFramesPerBlock * kWave) {
+    twc[i] = p.tw_cos[i];
+    tws[i] = p.tw_sin[i];
+  }
+  for (int i = threadIdx.x; i < p.win_len; i += kFramesPerBlock * kWave) win[i] = p.window[i];
+  for (int i = threadIdx.x; i < p.nmel * kMelRun; i += kFramesPerBlock * kWave) {
+    const int m = i / kMelRun, k = p.mel_lo[m] + (i - m * kMelRun);
+    melw[i] = k < p.mel_hi[m] ? p.mel_w[(int64_t)m * (NFFT / 2 + 1) + k] : 0.f;
+  }
   const int64_t q0 = frame0 * p.hop - 1;                       // sig[i] = padded signal at index q0 + i (clamped at 0)
   for (int i = threadIdx.x; i < nsig; i += kFramesPerBlock * kWave) {
     int64_t q = q0 + i;
@@ -79,7 +97,7 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
   const float* sw = sig + w * p.hop;       // sw[i + 1] = sample(frame * hop + i), sw[i] = the sample before it
   for (int i = lane; i < NFFT; i += kWave) {
     float v = 0.f;
-    if (live && i < p.win_len) v = (sw[i + 1] - p.preemph * sw[i]) * p.window[i];
+    if (live && i < p.win_len) v = (sw[i + 1] - p.preemph * sw[i]) * win[i];
     const int j = __brev((unsigned)i) >> (32 - p.log2_nfft);
     re[w][j] = v;
     im[w][j] = 0.f;
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
     for (int k = lane; k < NFFT / 2; k += kWave) {
       const int grp = k >> s, pos = k & (half - 1);
       const int i0 = (grp << (s + 1)) + pos, i1 = i0 + half;
-      const float c = p.tw_cos[pos * tstride], sn = p.tw_sin[pos * tstride];  // e^{-2 pi i pos / (2 half)}
+      const float c = twc[pos * tstride], sn = tws[pos * tstride];  // e^{-2 pi i pos / (2 half)}
       const float ar = re[w][i0], ai = im[w][i0], br = re[w][i1], bi = im[w][i1];
       const float tr = br * c + bi * sn, ti = bi * c - br * sn;
       re[w][i0] = ar + tr; im[w][i0] = ai + ti;
@@ -122,7 +140,9 @@ __global__ __launch_bounds__(kFramesPerBlock* kWave) void logmel_kernel(MelParam
       float acc = 0.f;
       if (live) {
         const float* wrow = p.mel_w + (int64_t)m * nb;
-        for (int k = p.mel_lo[m]; k < p.mel_hi[m]; ++k) acc += wrow[k] * re[w][k];
+        const int lo = p.mel_lo[m], hi = p.mel_hi[m], run = min(hi, lo + kMelRun);
+        for (int k = lo; k < run; ++k) acc += melw[m * kMelRun + (k - lo)] * re[w][k];      // same products, same order
+        for (int k = run; k < hi; ++k) acc += wrow[k] * re[w][k];
         acc = logf(fmaxf(acc, p.log_floor));
       }
       stage[m * kFramesPerBlock + w] = live ? acc : 0.f;  // Pad: fill 0
@@ -250,7 +270,8 @@ extern "C" int caiman_logmel_forward(const float* audio, const int32_t* audio_le
               win_len, hop, nfft, lg, nmel, initial_pad, preemph, dither, log_floor, seed};
   const dim3 grid((unsigned)((max_frames + kFramesPerBlock - 1) / kFramesPerBlock), (unsigned)B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t sig_bytes = (size_t)((kFramesPerBlock - 1) * hop + win_len + 1) * sizeof(float);
+  const size_t sig_bytes = (size_t)((((kFramesPerBlock - 1) * hop + win_len + 1 + 3) & ~3) + nfft + ((win_len + 3) & ~3) +
+                                    nmel * kMelRun) * sizeof(float);
   CAIMAN_CHECK(nmel <= nfft && sig_bytes + (size_t)2 * kFramesPerBlock * nfft * sizeof(float) <= 150 * 1024,
                "logmel_forward: nmel <= nfft and %d frames of hop %d / window %d must fit the block's sample buffer",
                kFramesPerBlock, hop, win_len);
