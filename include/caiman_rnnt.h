@@ -331,7 +331,9 @@ int caiman_proj_gemm(const caiman_proj_problem_t* problems, int n_problems, int 
  * C [M, N] = A [M, K] · W [N, K]^T + bias [N] (operands and C in `dtype`, bf16 / f16; fp32 accumulation); when `lse` is
  * given, lse[m] = log sum_n exp(C[m][n]) of the STORED (rounded) row, fp32, through `workspace`
  * (caiman_joint_fc_workspace_elems(M, N) floats).  lse == NULL: the plain product (the input gradient dY · W of the same
- * projection is this call with the transposed weight copy as W).  N % 256 == 0, K % 128 == 0, A / W rows 16-byte aligned.
+ * projection is this call with the transposed weight copy as W).  N % 256 == 0, K % 128 == 0, K >= 256; A, W and C
+ * 16-byte aligned, bias 8-byte.  `workspace` receives the per-64-column partial pairs as [2][N / 64][M] floats.
+ * One persistent workgroup per CU walks the 256 x 256 output tiles (CAIMAN_JOINT_WGS overrides the count).
  * ------------------------------------------------------------------------- */
 int64_t caiman_joint_fc_workspace_elems(int64_t M, int64_t N);
 int caiman_joint_fc_supported(int64_t M, int64_t N, int64_t K, int dtype);
@@ -339,8 +341,9 @@ int caiman_joint_fc_forward(const void* A, const void* W, const void* bias, void
                             int64_t M, int64_t N, int64_t K, int dtype, caiman_stream_t stream);
 /* Weight gradient of the same projection (csrc/joint_wgrad.hip) — replaces autograd's dW = dY^T . h of torch.nn.Linear
  * (training/caiman_asr_train/rnnt/model.py:409-439): dY [M, N], H [M, K] in `dtype`, the reduction over M split into
- * `slices` consecutive row ranges of `rows_per_slice` rows (a multiple of 32; caiman_joint_fc_wgrad_plan chooses both; 0 =
- * shape not supported: N, K % 256 == 0, bf16 / f16); slabs [slices][N][K] fp32 receives one partial product per slice
+ * `slices` consecutive row ranges of `rows_per_slice` rows (a multiple of 128 from caiman_joint_fc_wgrad_plan: pairs of the
+ * 8-phase kernel's 64-row tiles; multiples of 32 >= 96 are still accepted and run on the round-3 ring kernel; 0 slices =
+ * shape not supported: N, K % 256 == 0, M >= 256, bf16 / f16); slabs [slices][N][K] fp32 receives one partial product per slice
  * (written, not accumulated).  The caller adds the slabs in order, plus the product of the rows past slices * rows_per_slice. */
 int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice);
 int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
