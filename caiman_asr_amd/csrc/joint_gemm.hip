@@ -31,8 +31,10 @@
 //   type 2  W rows {wc * 64 + 32 .. 63}   (phases 1, 2)
 //   type 3  A rows {wr * 128 + 64 .. 127} (phases 2, 3)
 // Unit u = 4 * tile + type is issued at phase u - 6 by all eight waves (two 1 KB LDS-DMA instructions each), every phase ends
-// its load part with vmcnt(8) -- the four youngest units may still fly, unit <= phase + 2 has landed -- and unit u is first
-// read at phase u - 1 or u: one phase AFTER the wait that retires it, as waves staggered by a barrier need.  Unit u + 8
+// its load part with vmcnt(6) -- the three youngest units may still fly, unit <= phase + 3 has landed -- and unit u is first
+// read at phase u - 2 (type 1: a K tile's first W fragments are read in the read-free last phase of the tile before, which
+// evens the fragment reads out to 8 / 4 / 8 / 4 per phase), u - 1 or u: at least one phase AFTER the wait that retires it, as
+// waves staggered by a barrier need.  Unit u + 8
 // overwrites unit u at phase u + 2, two phases after the last read of u (type 0 is read at phase u).  Rows are 128 B; 16-byte
 // chunk c of row r sits at position c ^ ((r >> 1) & 7) (swizzle applied to the DMA's SOURCE address and to the read address):
 // the four 16-lane groups of a ds_read_b128 each hit 16 distinct bank groups.
@@ -244,10 +246,13 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
   int m0, n0, m0n = 0, n0n = 0;
   panels pc, pn;                                         // descriptors of the tile's A / W panels, and the next tile's
   int kb = 0;                                            // byte offset (in a row) of the K tile pair being multiplied
-  frag af[4][2], wf[2][2][2];
+  frag af[4][2], wf[2][2];     // A fragments of the current row half; W fragments of the nh = 1 column half
+  frag wz[2][2][2];        // [parity][a][ks]: the nh = 0 fragments of the K tile of that parity, read one phase early
 #ifdef JG_NO_READS
 #pragma unroll
-  for (int i = 0; i < 8; ++i) asm volatile("" : "=v"((&af[0][0])[i]), "=v"((&wf[0][0][0])[i]));   // defined, opaque
+  for (int i = 0; i < 8; ++i) asm volatile("" : "=v"((&af[0][0])[i]), "=v"((&wz[0][0][0])[i]));   // defined, opaque
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "=v"((&wf[0][0])[i]));
 #endif
 
   // one phase.  PAR: parity of the K tile being multiplied; PH: phase 0..3; SRC: 0 nothing to issue, 1 unit (phase + 6) of
@@ -260,22 +265,22 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
 #ifndef JG_NO_READS
     if constexpr (PH == 0) {
       const T* ua = CAIMAN_UNIT(PAR, 0);
-      const T* uw = CAIMAN_UNIT(PAR, 1);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wf[0][a][ks] = *reinterpret_cast<const frag*>(uw + wbase[ks] + a * 16 * 64);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) af[b][ks] = *reinterpret_cast<const frag*>(ua + abase[ks] + b * 16 * 64);
+    } else if constexpr (PH == 3) {      // the next K tile's first W unit (other parity), one phase ahead of its phase 0
+      const T* uw = CAIMAN_UNIT(PAR ^ 1, 1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wz[PAR ^ 1][a][ks] = *reinterpret_cast<const frag*>(uw + wbase[ks] + a * 16 * 64);
     } else if constexpr (PH == 1) {
       const T* uw = CAIMAN_UNIT(PAR, 2);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wf[1][a][ks] = *reinterpret_cast<const frag*>(uw + wbase[ks] + a * 16 * 64);
+        for (int ks = 0; ks < 2; ++ks) wf[a][ks] = *reinterpret_cast<const frag*>(uw + wbase[ks] + a * 16 * 64);
     } else if constexpr (PH == 2) {
       const T* ua = CAIMAN_UNIT(PAR, 3);
 #pragma unroll
@@ -313,14 +318,17 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) acc[mh][b][nh][a] = jmfma(wf[nh][a][ks], af[b][ks], acc[mh][b][nh][a]);
+        for (int a = 0; a < 2; ++a) {
+          if constexpr (nh == 0) acc[mh][b][nh][a] = jmfma(wz[PAR][a][ks], af[b][ks], acc[mh][b][nh][a]);
+          else acc[mh][b][nh][a] = jmfma(wf[a][ks], af[b][ks], acc[mh][b][nh][a]);
+        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
   using VN = IC<-1>;
-  using V8 = IC<8>;
+  using V8 = IC<6>;        // vmcnt(6) behind every issue: the three youngest units may still fly, unit <= phase + 3 has landed
   using I0 = IC<0>;
   using I1 = IC<1>;
   using I2 = IC<2>;
@@ -346,6 +354,12 @@ __global__ __launch_bounds__(512, 2) void joint_fc_gemm8_kernel(const T* __restr
   __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  // the first tile's first W unit: every later one is read by the phase 3 in front of it (the last phase of a tile reads
+  // the next tile's)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wz[0][a][ks] = *reinterpret_cast<const frag*>(u01 + wbase[ks] + a * 16 * 64);
 
   for (;;) {
     const int tnext = t + t_step;
