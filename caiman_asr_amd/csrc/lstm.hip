@@ -227,6 +227,9 @@ struct FwdSlots {
   float drop_p[kMaxSlots];
   int hidden[kMaxSlots];  // 0: the launch's H; otherwise this slot's own (smaller) hidden size
   uint64_t seed;
+  // B <= 32 resident kernels working on a 32-row slice of a larger batch (res_batch_slice): rows of the whole batch
+  // between two timesteps of g / c / y / ymask, and the batch the rings are sized for.  0: the launch's B.
+  int batch_stride;
 };
 
 template <typename T>
@@ -249,6 +252,7 @@ struct BwdSlots {
   int hidden[kMaxSlots];  // as in FwdSlots
   float* dbias[kMaxSlots];  // NULL, or fp32 [4H] (interleaved layout): += sum over the call's dG rows
   uint64_t seed;
+  int batch_stride;  // as in FwdSlots
 };
 
 // ---- forward step: grid (H/4, ceil(B/32), slots), 256 threads = 4 waves -----------------------
@@ -643,7 +647,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
   const int nwg = NKS;
   unsigned* cnt = sync + slot * kResCounterStride;
   unsigned* fail_dev = sync + kMaxSlots * kResCounterStride;
-  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int Bs = w.batch_stride ? w.batch_stride : B;   // rows between timesteps (a slice of a larger batch: res_batch_slice)
+  const int64_t go = (int64_t)Bs * 4 * H, so = (int64_t)Bs * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int u0 = j * 32 + wave * 8;   // first hidden unit of this wave
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident(FwdSlots<T> w, int B
           *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
         }
         if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
-          const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+          const int64_t hsz = (int64_t)((Bs + 31) / 32 * 32) * H;
           T* h_out = w.hring[slot] + ((w.parity[slot] + nsteps) & 1) * hsz;
           *reinterpret_cast<g4*>(h_out + tiled_index(b, u0 + half * 4, NKS)) = hv;
         }
@@ -1410,7 +1415,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_dma(FwdSlots<T> w, i
   const int nwg = NKS;
   unsigned* cnt = sync + slot * kResCounterStride;
   unsigned* fail_dev = sync + kMaxSlots * kRes2CtrPerSlot * kResCounterStride;
-  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int Bs = w.batch_stride ? w.batch_stride : B;   // rows between timesteps (a slice of a larger batch: res_batch_slice)
+  const int64_t go = (int64_t)Bs * 4 * H, so = (int64_t)Bs * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int u0 = j * 32 + wave * 8;   // first hidden unit of this wave
@@ -1593,7 +1599,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_resident_dma(FwdSlots<T> w, i
           *reinterpret_cast<g4*>(w.ymask[slot] + so * s + e) = mv;
         }
         if (s == nsteps - 1) {   // leave the ring as the step kernels expect it
-          const int64_t hsz = (int64_t)((B + 31) / 32 * 32) * H;
+          const int64_t hsz = (int64_t)((Bs + 31) / 32 * 32) * H;
           T* h_out = w.hring[slot] + ((w.parity[slot] + nsteps) & 1) * hsz;
           *reinterpret_cast<g4*>(h_out + tiled_index(b, u0 + half * 4, NKS)) = hv;
         }
@@ -1663,7 +1669,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
   const int nwg = NKS;
   unsigned* cnt = sync + slot * kResCounterStride;
   unsigned* fail_dev = sync + kMaxSlots * kResCounterStride;
-  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int Bs = w.batch_stride ? w.batch_stride : B;   // rows between timesteps (a slice of a larger batch: res_batch_slice)
+  const int64_t go = (int64_t)Bs * 4 * H, so = (int64_t)Bs * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int rt = wave & 1, kh = wave >> 1;
@@ -1865,7 +1872,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident(BwdSlots<T> w, int B
       res_store16(o0, ro, (int)(eoff * 4) * (int)sizeof(T));
       res_store16(o1, ro, (int)(eoff * 4 + 8) * (int)sizeof(T));
       if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
-        const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+        const int64_t dsz = (int64_t)((Bs + 31) / 32 * 32) * 4 * H;
         T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
         *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4, 4 * NKS)) = o0;
         *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4 + 8, 4 * NKS)) = o1;
@@ -1976,7 +1983,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
   unsigned* gc = sync + (slot * kRes2CtrPerSlot + 4 + jq) * kResCounterStride;
   unsigned* fail_dev = sync + kMaxSlots * kRes2CtrPerSlot * kResCounterStride;
   float* pslot = pws + (size_t)slot * kRes2PartialFloatsPerSlot;
-  const int64_t go = (int64_t)B * 4 * H, so = (int64_t)B * H;
+  const int Bs = w.batch_stride ? w.batch_stride : B;   // rows between timesteps (a slice of a larger batch: res_batch_slice)
+  const int64_t go = (int64_t)Bs * 4 * H, so = (int64_t)Bs * H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, kg = lane >> 4;
 
@@ -2208,7 +2216,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_resident2(BwdSlots<T> w, int 
       res_store16(o0, ro, (int)(eoff * 4u) * (int)sizeof(T));
       res_store16(o1, ro, (int)(eoff * 4u + 8u) * (int)sizeof(T));
       if (s == nsteps - 1) {   // leave the ring and dC as the step kernels expect them
-        const int64_t dsz = (int64_t)((B + 31) / 32 * 32) * 4 * H;
+        const int64_t dsz = (int64_t)((Bs + 31) / 32 * 32) * 4 * H;
         T* dG_out = w.dring[slot] + ((w.parity[slot] + s) & 1) * dsz;
         *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4, 4 * NKS)) = o0;
         *reinterpret_cast<frag*>(dG_out + tiled_index(eb, u * 4 + 8, 4 * NKS)) = o1;
@@ -3030,6 +3038,7 @@ template <typename S>
 inline S res_slot_group(const S& w, int first, int count) {
   S g{};
   g.seed = w.seed;
+  g.batch_stride = w.batch_stride;
   auto cp = [&](auto S::*field) {
     for (int i = 0; i < count; ++i) (g.*field)[i] = (w.*field)[first + i];
   };
@@ -3056,6 +3065,42 @@ inline int res_wide_kb(bool backward) {
   static const int forced = std::getenv("CAIMAN_LSTM_WIDE_KB") ? std::atoi(std::getenv("CAIMAN_LSTM_WIDE_KB")) : 0;
   if (forced == 1 || forced == 2) return forced;
   return backward ? 1 : 2;
+}
+
+// Batches the batch-tile kernels do not take (B > 32 with H = 768 or 1536, or more tiles than they hold): the B <= 32
+// kernels run once per slice of 32 batch rows.  A slice is an independent recurrence, so its launch gets the slot
+// pointers moved to the slice's first row and `batch_stride` = the whole batch; the ring halves are tiled by 32 rows
+// (tiled_index), so slice i is tile i of either half.  The weights are loaded once per slice instead of once per call
+// (H = 1536: 18.9 MB per layer from L2/HBM, ~3 % of a 24-step call).
+template <typename T>
+inline FwdSlots<T> res_batch_slice(const FwdSlots<T>& w, int n_slots, int64_t B, int64_t H, int64_t b0) {
+  FwdSlots<T> g = w;
+  g.batch_stride = (int)B;
+  for (int i = 0; i < n_slots; ++i) {
+    g.g[i] += b0 * 4 * H; g.c[i] += b0 * H; g.y[i] += b0 * H; g.hring[i] += b0 * H;
+    if (g.ymask[i]) g.ymask[i] += b0 * H;
+    g.drop_base[i] += (uint64_t)(b0 * H);
+  }
+  return g;
+}
+template <typename T>
+inline BwdSlots<T> res_batch_slice(const BwdSlots<T>& w, int n_slots, int64_t B, int64_t H, int64_t b0) {
+  BwdSlots<T> g = w;
+  g.batch_stride = (int)B;
+  for (int i = 0; i < n_slots; ++i) {
+    g.g[i] += b0 * 4 * H; g.c[i] += b0 * H; g.delta[i] += b0 * g.d_sb[i]; g.dG[i] += b0 * 4 * H;
+    g.dring[i] += b0 * 4 * H; g.dC[i] += b0 * H;
+    g.drop_base[i] += (uint64_t)(b0 * H);
+  }
+  return g;
+}
+// shapes served slice by slice: what the B <= 32 kernels take and the batch-tile kernels (H = 512, 1024 up to
+// 32 * kResMaxTiles rows) do not
+inline bool res_sliced_shape(int64_t B, int64_t H) {
+  static const bool off = std::getenv("CAIMAN_LSTM_BATCH_SLICES") != nullptr && std::atoi(std::getenv("CAIMAN_LSTM_BATCH_SLICES")) == 0;
+  if (off || B <= 32) return false;
+  if ((H == 512 || H == 1024) && B <= 32 * kResMaxTiles) return false;
+  return true;
 }
 
 // true when the launch was taken by the resident kernel
@@ -3122,6 +3167,25 @@ bool try_fwd_resident(const FwdSlots<T>& w_all, int n_slots_all, int n_launches,
     }
     res_end(st, s);
     *err = check_launch("lstm resident forward");
+    if (*err != CAIMAN_OK) return true;
+  }
+  return true;
+}
+
+// B > 32 outside the batch-tile kernels' shapes: one B <= 32 launch (group) per 32-row slice, in stream order
+template <typename T, bool HARD>
+bool try_fwd_resident_slices(const FwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!res_sliced_shape(B, H)) return false;
+  for (int64_t b0 = 0; b0 < B; b0 += 32) {
+    const FwdSlots<T> ws = res_batch_slice(w, n_slots, B, H, b0);
+    if (!try_fwd_resident<T, HARD>(ws, n_slots, n_launches, std::min<int64_t>(32, B - b0), H, s, err)) {
+      if (b0 == 0) return false;   // not admitted: nothing has been launched
+      // only a hand-off failure between two slices ends up here; the earlier slices have overwritten their gates
+      set_error("lstm resident forward: slice at row %lld refused after earlier slices ran", (long long)b0);
+      *err = CAIMAN_ERR_LAUNCH;
+      return true;
+    }
     if (*err != CAIMAN_OK) return true;
   }
   return true;
@@ -3227,6 +3291,25 @@ bool try_bwd_resident2(const BwdSlots<T>& w_all, int n_slots_all, int n_launches
 #undef CAIMAN_RES2
     res_end(st, s);
     *err = check_launch("lstm resident backward (2-D split)");
+    if (*err != CAIMAN_OK) return true;
+  }
+  return true;
+}
+
+template <typename T, bool HARD>
+bool try_bwd_resident_slices(const BwdSlots<T>& w, int n_slots, int n_launches, int64_t B, int64_t H, hipStream_t s, int* err) {
+  *err = CAIMAN_OK;
+  if (!res_sliced_shape(B, H)) return false;
+  for (int64_t b0 = 0; b0 < B; b0 += 32) {
+    const BwdSlots<T> ws = res_batch_slice(w, n_slots, B, H, b0);
+    const int64_t rows = std::min<int64_t>(32, B - b0);
+    if (!try_bwd_resident2<T, HARD>(ws, n_slots, n_launches, rows, H, s, err) &&
+        !try_bwd_resident<T, HARD>(ws, n_slots, n_launches, rows, H, s, err)) {
+      if (b0 == 0) return false;
+      set_error("lstm resident backward: slice at row %lld refused after earlier slices ran", (long long)b0);
+      *err = CAIMAN_ERR_LAUNCH;
+      return true;
+    }
     if (*err != CAIMAN_OK) return true;
   }
   return true;
@@ -3585,13 +3668,14 @@ extern "C" int caiman_lstm_resident_profile(uint32_t* out10) {
 extern "C" int caiman_lstm_resident_would_run(int64_t B, int64_t H, int n_slots) {
   using namespace caiman;
   if (!g_res_mode.load(std::memory_order_relaxed) || B < 1 || H % 32 != 0 || n_slots < 1 || n_slots > kMaxSlots) return 0;
-  if (B > 32 && (B > 32 * kResMaxTiles || (H != 512 && H != 1024))) return 0;   // batch tiles: the backward kernel's shapes
+  const bool sliced = res_sliced_shape(B, H);   // B > 32 outside the batch-tile kernels' shapes: 32-row slices of the B <= 32 kernels
+  if (B > 32 && !sliced && (B > 32 * kResMaxTiles || (H != 512 && H != 1024))) return 0;
   const int nks = (int)(H / 32);
   if (!(nks == 2 || nks == 4 || nks == 8 || nks == 16 || nks == 24 || nks == 32 || nks == 48)) return 0;
   ResState* st = res_state();
   if (!st || *reinterpret_cast<volatile unsigned*>(st->fail_host) != 0u) return 0;
   // B <= 32: slots that do not fit the chip together go out as consecutive launches; the batch-tile kernels do not split
-  return (B <= 32 ? nks <= st->cus : (int64_t)n_slots * nks <= st->cus) ? 1 : 0;
+  return (B <= 32 || sliced ? nks <= st->cus : (int64_t)n_slots * nks <= st->cus) ? 1 : 0;
 }
 
 // Wave calls served by a resident launch since the library was loaded (callers that account launches and bytes
@@ -3662,6 +3746,9 @@ extern "C" int caiman_lstm_wave_fwd(const caiman_lstm_fwd_slot_t* slots, int n_s
       if (hard ? try_fwd_resident<T, true>(w, n_slots, n_launches, B, H, s, &err)
                : try_fwd_resident<T, false>(w, n_slots, n_launches, B, H, s, &err))
         return err;
+      if (hard ? try_fwd_resident_slices<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_fwd_resident_slices<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
     }
     if (gate_layout)
       return hard ? launch_fwd_waves<T, true, true>(w, n_slots, n_launches, B, H, s)
@@ -3712,6 +3799,9 @@ extern "C" int caiman_lstm_wave_bwd(const caiman_lstm_bwd_slot_t* slots, int n_s
         return err;
       if (hard ? try_bwd_resident<T, true>(w, n_slots, n_launches, B, H, s, &err)
                : try_bwd_resident<T, false>(w, n_slots, n_launches, B, H, s, &err))
+        return err;
+      if (hard ? try_bwd_resident_slices<T, true>(w, n_slots, n_launches, B, H, s, &err)
+               : try_bwd_resident_slices<T, false>(w, n_slots, n_launches, B, H, s, &err))
         return err;
     }
     if (gate_layout)

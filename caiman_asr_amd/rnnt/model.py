@@ -227,8 +227,9 @@ class RNNT(nn.Module):
     @staticmethod
     def _resident_batch_chunks(B, hidden, n_layers):
         """[(lo, hi), ...] in steps of 32 when the weight-resident LSTM kernels would not take a batch of B at this hidden
-        size but do take 32 (csrc/lstm.hip: batch-tile kernels exist for H = 512 and 1024; H = 1536 / 768, the large-196M
-        model, has the B <= 32 kernels only), else None.  CAIMAN_BATCH_CHUNKS=0 turns the chunking off (A/B)."""
+        size but do take 32, else None.  The library now slices such batches itself (csrc/lstm.hip::res_batch_slice: the
+        B <= 32 kernels once per 32 rows, everything else of the step at the full batch), so this only applies with
+        CAIMAN_LSTM_BATCH_SLICES=0 (the round-4 A/B).  CAIMAN_BATCH_CHUNKS=0 turns the chunking off."""
         import os
 
         if B <= 32 or os.environ.get("CAIMAN_BATCH_CHUNKS", "1") == "0":

@@ -306,7 +306,11 @@ def _run_stack(m, x, h0, c0, w, dtype, mode):
 
 @pytest.mark.parametrize("T,B,I,H,L,p", [(40, 3, 16, 64, 2, 0.0), (70, 32, 48, 128, 3, 0.0), (150, 17, 64, 256, 4, 0.0),
                                          (90, 8, 64, 512, 3, 0.3), (50, 32, 64, 768, 2, 0.2), (70, 32, 64, 1024, 3, 0.0),
-                                         (70, 64, 64, 512, 3, 0.2), (45, 128, 64, 1024, 2, 0.0), (40, 77, 32, 1024, 2, 0.1)])
+                                         (70, 64, 64, 512, 3, 0.2), (45, 128, 64, 1024, 2, 0.0), (40, 77, 32, 1024, 2, 0.1),
+                                         # B > 32 outside the batch-tile kernels' shapes: 32-row slices of the B <= 32
+                                         # kernels (res_batch_slice); T = 49 ends on a one-step tick that reads the ring
+                                         (49, 64, 64, 768, 2, 0.2), (49, 100, 64, 1536, 2, 0.1), (49, 40, 32, 128, 3, 0.3),
+                                         (30, 160, 32, 512, 2, 0.0)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_resident_chunk_kernels_match_step_kernels(T, B, I, H, L, p, dtype):
     """csrc/lstm.hip, weight-resident chunk kernels: one launch runs every timestep of a pipeline tick, the
@@ -342,7 +346,7 @@ def test_resident_chunk_kernels_match_step_kernels(T, B, I, H, L, p, dtype):
 def test_resident_kernels_under_uneven_load_and_fallbacks():
     """Hand-offs must not depend on timing or placement: repeat a resident run while another stream keeps part of
     the chip busy with copies and compare bit for bit with the quiet run.  Shapes the resident kernels do not take
-    (B > 32) keep the per-timestep launches."""
+    (hidden sizes without a resident kernel) keep the per-timestep launches."""
     from caiman_asr_amd import _lib
     from caiman_asr_amd.rnnt_ext.custom_lstm.lstm import CustomLSTM
 
@@ -367,15 +371,17 @@ def test_resident_kernels_under_uneven_load_and_fallbacks():
         for a, b in zip(quiet, busy):
             assert torch.equal(a, b)
     assert _lib.lib().caiman_lstm_resident_failures() == 0
-    # B > 32: tiles of 32 batch rows at H = 512 / 1024 (resident), per-timestep launches at other hidden sizes
+    # B > 32: tiles of 32 batch rows at H = 512 / 1024, 32-row slices of the B <= 32 kernels at the other resident
+    # hidden sizes; per-timestep launches where no resident kernel exists (H = 96)
     xb = torch.randn(T, 40, I, device=DEV)
     _, n = _run_stack(m, xb, torch.zeros(L, 40, H, device=DEV), torch.zeros(L, 40, H, device=DEV),
                       torch.randn(T, 40, H, device=DEV), torch.bfloat16, 1)
     assert n > 0
-    m2 = CustomLSTM(I, 128, 2, device=DEV)
-    _, n = _run_stack(m2, xb, torch.zeros(2, 40, 128, device=DEV), torch.zeros(2, 40, 128, device=DEV),
-                      torch.randn(T, 40, 128, device=DEV), torch.bfloat16, 1)
-    assert n == 0
+    for Hs, resident in ((128, True), (96, False)):
+        m2 = CustomLSTM(I, Hs, 2, device=DEV)
+        _, n = _run_stack(m2, xb, torch.zeros(2, 40, Hs, device=DEV), torch.zeros(2, 40, Hs, device=DEV),
+                          torch.randn(T, 40, Hs, device=DEV), torch.bfloat16, 1)
+        assert (n > 0) == resident, (Hs, n)
 
 
 def test_fused_bias_gradient_on_the_per_timestep_path(monkeypatch):
