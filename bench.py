@@ -321,7 +321,10 @@ def feed_beside_step(step, args, dev, first_index):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    # 30 = five passes over the six synthetic batches (0.75 s timed): the GPU boxes show a one-off ~20 ms stall in about one
+    # run out of three (any step, either tree in an A/B: `step_ms_device` in the JSON line shows it); over 12 steps that
+    # is +1.7 ms on the average, over 30 steps +0.7
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--model", choices=["base", "large"], default="base",
@@ -514,6 +517,16 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    # The timed loop lets the host run two steps ahead of the device, so the caching allocator must hold up to three steps'
+    # activations where the synchronised warm-up steps needed one: without room in its pool a timed step stops for a
+    # hipMalloc of several GB (measured: one step of 50 ms instead of 31 in some runs and not in others, +1.1 ms on the
+    # 12-step average).  A training run reaches that high-water mark within its first steps; reach it here, before the clock.
+    peak = torch.cuda.max_memory_allocated(dev)
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    room = min(int(2.5 * peak), int(0.5 * free_b))
+    if room > (1 << 20):
+        pool_pad = torch.empty(room, dtype=torch.uint8, device=dev)
+        del pool_pad
     barrier()
     if reducer is not None:
         reducer.exposed_ms()   # drop the warm-up steps' events
@@ -525,6 +538,9 @@ def main():
     in_flight = []   # the host may run at most two steps ahead of the device (a real loop reads the loss now and then);
     #                  unbounded run-ahead makes the allocator hold every queued step's activations at once
     host_wait = host_issue = 0.0   # host blocked on the run-ahead limit | host queuing a step's commands
+    step_ends = []                 # one event per step on the device clock: shows a single slow step inside the average
+    issue_ms = []                  # host time to queue each step
+    segs0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)   # hipMalloc calls of the caching allocator so far
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -535,9 +551,11 @@ def main():
         last_loss, a, c, ntok = step(args.warmup + i, args.warmup + i)
         pred_tokens += ntok
         host_issue += time.perf_counter() - tq
-        done = torch.cuda.Event()
+        issue_ms.append(round(1e3 * (time.perf_counter() - tq), 2))
+        done = torch.cuda.Event(enable_timing=True)
         done.record(main_stream if args.main_priority != 0 else torch.cuda.current_stream())
         in_flight.append(done)
+        step_ends.append(done)
         audio_s += a
         cells += c
         if args.debug_steps:
@@ -588,6 +606,10 @@ def main():
         # waits `wait_for_device` ms per step for the device to catch up (run-ahead limit of two steps)
         out["host_ms_per_step"] = {"issue": round(host_issue / args.steps * 1e3, 2),
                                    "wait_for_device": round(host_wait / args.steps * 1e3, 2)}
+        # device-clock time between the ends of consecutive steps (the first timed step has no predecessor event)
+        out["host_issue_ms"] = issue_ms
+        out["allocator_segments_added_in_timed_loop"] = int(torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - segs0)
+        out["step_ms_device"] = [round(step_ends[j - 1].elapsed_time(step_ends[j]), 2) for j in range(1, len(step_ends))]
         # ---- the whole step against the chip (SURVEY section 8(d) formulas; training = 3 x forward for the GEMM terms):
         # encoder 2.748 GFLOP per audio-second, prediction + joint_pred 9.175 MFLOP per token (+ SOS), joint 13.369 MFLOP per
         # lattice cell (large-196M: 6.128 / 20.45 / 35.65).  Algorithmic HBM bytes: the logits cross HBM six times per cell
@@ -715,17 +737,18 @@ def main():
             # torch operators grouped by their Python call stack: launches and device time per step of every (operator, innermost
             # frame of this repository) pair
             n, agg = args.launch_sources, {}
-            for e in prof.key_averages(group_by_stack_n=12):
+            for e in prof.key_averages(group_by_stack_n=30):
                 dev_us = getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)
                 if dev_us <= 0 or not e.key.startswith("aten::"):
                     continue
-                src = next((f for f in e.stack if ("caiman_asr_amd" in f or "bench.py" in f) and "_lib.py" not in f), "?")
-                src = src.split("caiman-asr/")[-1].split("repo/")[-1]
-                a = agg.setdefault((e.key, src[:120]), [0, 0.0])
+                # the first three frames of this repository in the order the profiler lists them (innermost first)
+                mine = [f for f in e.stack if ("caiman_asr_amd" in f or "bench.py" in f) and "_lib.py" not in f][:3]
+                src = " < ".join(f.split("caiman_asr_amd/")[-1].split("repo/")[-1] for f in mine) or "?"
+                a = agg.setdefault((e.key, src[:150]), [0, 0.0])
                 a[0] += e.count
                 a[1] += e.self_device_time_total if hasattr(e, "self_device_time_total") else dev_us
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-            for (op, src), (cnt, us) in rows[:70]:
+            for (op, src), (cnt, us) in rows[:110]:
                 print(f"[launch sources] {us / n:8.1f} us {cnt / n:6.1f} x  {op:34s} {src}", file=sys.stderr)
         if world == 1 and args.feed:
             try:

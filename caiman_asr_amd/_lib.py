@@ -153,6 +153,7 @@ _SIGS = {
     "caiman_joint_fc_wgrad": ([P, P, P, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_wgrad_tn_plan": ([I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_wgrad_tn_estimate_us": ([I64, I64, I64, I32, I32], ctypes.c_double),
+    "caiman_wgrad_tn_covers_remainder": ([I64, I64, I64, I32, I64], ctypes.c_int),
     "caiman_wgrad_tn": ([P, I64, P, I64, P, I32, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_wgrad_tn2": ([P, I64, P, I64, I32, P, I64, P, I64, I32, P, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_proj_gemm": ([P, I32, I32, I32, P], ctypes.c_int),
@@ -177,6 +178,8 @@ _SIGS = {
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),
+    "caiman_lstm_last_states": ([P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, I32, I32, P, P, P], ctypes.c_int),
+    "caiman_specaug_geometry": ([P, P, I32, I64, I64, I64, I32, F32, F32, F32, I32, F32, F32, P, P], ctypes.c_int),
     "caiman_specaug_splice": ([P, I64, I64, I64, P, P, I32, P, P, I32, I32, I32, I64, P, P], ctypes.c_int),
     "caiman_joint_forward": ([P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, F64, ctypes.c_uint64, I32, P, P],
                              ctypes.c_int),

@@ -249,6 +249,42 @@ __global__ __launch_bounds__(256) void specaug_splice_kernel(const float* __rest
   }
 }
 
+// SpecAugment mask geometry from uniform draws, one thread per (utterance, mask index): float arithmetic in the order
+// data/features.py::SpecAugment.geometry_from_draws performs it (torch.floor / torch.round = floorf / rintf), so the two
+// agree bit for bit on the same draws.  rnd [B][2 nf + 2 nt]: columns fw | f0 | tw | t0;  out: fw [B][nf], f0 [B][nf],
+// tw [B][nt], t0 [B][nt], one after the other.
+__global__ __launch_bounds__(256) void specaug_geometry_kernel(const float* __restrict__ rnd, const void* __restrict__ lens,
+                                                               int lens_kind, int B, float F, float T, int nf, float min_freq,
+                                                               float freq_span, float time_masks, int nt, float min_time,
+                                                               float max_time, float* __restrict__ out) {
+  const int per = nf > nt ? nf : nt;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * per) return;
+  const int b = idx / per, j = idx % per;
+  const int cols = 2 * nf + 2 * nt;
+  const float* r = rnd + (int64_t)b * cols;
+  float* fw = out;
+  float* f0 = fw + (int64_t)B * nf;
+  float* tw = f0 + (int64_t)B * nf;
+  float* t0 = tw + (int64_t)B * nt;
+  if (j < nf) {
+    const float w = floorf(r[j] * freq_span) + min_freq;
+    const float room = fmaxf((F - w) + 1.f, 1.f);
+    fw[(int64_t)b * nf + j] = w;
+    f0[(int64_t)b * nf + j] = floorf(r[nf + j] * room);
+  }
+  if (j < nt) {
+    const float len = lens_kind == 0 ? (float)static_cast<const int32_t*>(lens)[b]
+                      : lens_kind == 1 ? (float)static_cast<const int64_t*>(lens)[b] : static_cast<const float*>(lens)[b];
+    const float n_masks = (time_masks > 0.f && time_masks < 1.f) ? rintf(len * time_masks) : time_masks;
+    const float max_t = (max_time > 0.f && max_time < 1.f) ? rintf(len * max_time) : max_time;
+    const float w = floorf(r[2 * nf + j] * ((max_t - min_time) + 1.f)) + min_time;
+    const float room = fmaxf((T - w) + 1.f, 1.f);
+    tw[(int64_t)b * nt + j] = (float)j < n_masks ? w : 0.f;
+    t0[(int64_t)b * nt + j] = floorf(r[2 * nf + nt + j] * room);
+  }
+}
+
 }  // namespace
 }  // namespace caiman
 
@@ -300,6 +336,21 @@ extern "C" int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int
   hipLaunchKernelGGL(mel_normalize_kernel, dim3((unsigned)nmel, (unsigned)B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, len, T, nmel, ds_mean, ds_std, ratio);
   return check_launch("caiman_mel_normalize");
+}
+
+extern "C" int caiman_specaug_geometry(const float* rnd, const void* lens, int lens_kind, int64_t B, int64_t F, int64_t T,
+                                       int nf, float min_freq, float freq_span, float time_masks, int nt, float min_time,
+                                       float max_time, float* out, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(B >= 1 && B <= 65535 && F >= 1 && T >= 1, "specaug_geometry: bad extents");
+  CAIMAN_CHECK(nf >= 0 && nt >= 0 && nf + nt >= 1 && nf <= 1024 && nt <= 65536, "specaug_geometry: mask counts");
+  CAIMAN_CHECK(rnd && out && (nt == 0 || lens), "specaug_geometry: null pointer");
+  CAIMAN_CHECK(lens_kind >= 0 && lens_kind <= 2, "specaug_geometry: lens_kind 0 (int32), 1 (int64) or 2 (float)");
+  const int64_t n = B * (nf > nt ? nf : nt);
+  hipLaunchKernelGGL(specaug_geometry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     rnd, lens, lens_kind, (int)B, (float)F, (float)T, nf, min_freq, freq_span, time_masks, nt,
+                     min_time, max_time, out);
+  return check_launch("caiman_specaug_geometry");
 }
 
 extern "C" int caiman_specaug_splice(const float* x, int64_t B, int64_t F, int64_t T, const float* f0, const float* fw, int nf,

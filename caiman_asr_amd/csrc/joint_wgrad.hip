@@ -251,7 +251,8 @@ __global__ __launch_bounds__(512, 2) void joint_wgrad8_kernel(const T* __restric
                                                               float* __restrict__ slabs, int N, int K, int rows_per_slice,
                                                               int tiles_k, int n_tiles, int slices, int64_t stride_y,
                                                               int64_t stride_h, int split, const T* __restrict__ dY2,
-                                                              int64_t stride_y2, const T* __restrict__ Hm2, int64_t stride_h2) {
+                                                              int64_t stride_y2, const T* __restrict__ Hm2, int64_t stride_h2,
+                                                              int64_t rows_total) {
   using frag = typename wfrag<T>::type;
   constexpr int UE = 64 * 128;
   __shared__ __attribute__((aligned(1024))) T u00[UE], u01[UE], u02[UE], u03[UE], u10[UE], u11[UE], u12[UE], u13[UE];
@@ -286,13 +287,19 @@ __global__ __launch_bounds__(512, 2) void joint_wgrad8_kernel(const T* __restric
     srcy[i] = (unsigned)((r * N + (cu >> 6) * 128 + (cu & 63)) * (int)sizeof(T));
     srch[i] = (unsigned)((r * K + (cu >> 5) * 64 + (cu & 31)) * (int)sizeof(T));
   }
-  auto rsrc = [&](const T* base) {
+  // The descriptors end with the operand's last row: the last slice also takes the rows the slices do not cover
+  // (rows_total - slices * rows_per_slice of them, fewer than 128 per slice), rounded up to whole pairs of tiles -- the rows
+  // past the end read as zeros (an out-of-range buffer load returns 0, and that is what LDS-DMA writes), exact in the sum.
+  auto rsrc = [&](const T* base, int64_t valid_elems) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);
     const uint64_t u = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(u), 0, -1, 0x00020000);
+    const int64_t bytes = valid_elems * (int64_t)sizeof(T);
+    const unsigned rec = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(u), 0, (int)rec, 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t ry = rsrc(dY + m_begin * N + n0), rh = rsrc(Hm + m_begin * K + k0);
+  const int64_t rows_left = rows_total - m_begin;     // rows of this product from the slice's first row to the end
+  const __amdgpu_buffer_rsrc_t ry = rsrc(dY + m_begin * N + n0, rows_left * N - n0), rh = rsrc(Hm + m_begin * K + k0, rows_left * K - k0);
   const unsigned ystep = (unsigned)(64 * N * (int)sizeof(T)), hstep = (unsigned)(64 * K * (int)sizeof(T));   // one tile of m
   unsigned yb = 0, hb = 0;        // byte offsets of the first tile of the pair being multiplied
 
@@ -390,7 +397,8 @@ __global__ __launch_bounds__(512, 2) void joint_wgrad8_kernel(const T* __restric
   using I0 = IC8<0>; using I1 = IC8<1>; using I2 = IC8<2>; using I3 = IC8<3>;
   using VN = IC8<-1>; using V8 = IC8<8>;
 
-  const int nk = rows_per_slice / 64;     // even, at least four
+  // tiles of 64 rows: even, at least four; the last slice runs on to the operand's end
+  const int nk = slice == slices - 1 ? (int)((rows_left + 127) / 128) * 2 : rows_per_slice / 64;
   issue(I0{}, I0{}, 0u, 0u);
   issue(I0{}, I1{}, 0u, 0u);
   issue(I0{}, I2{}, 0u, 0u);
@@ -465,10 +473,11 @@ int wgrad_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* r
   }();
   // (round 4: slices are multiples of 128 rows -- pairs of the 8-phase kernel's 64-row tiles; 1.40 us per tile and 35 us per
   // round of workgroups fitted to tools/wgrad_tn_bench.py: 153 / 443 / 597 / 1391 us measured for 1 x 17 792, 5 and 6 x 8 896, 6 x 35 584 rows)
+  // (the rows the slices do not cover -- fewer than 128 per slice -- ride in the last slice: its workgroups decide the round)
   auto cost = [&](int64_t c) {
-    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (128 * c) * 2, rest = M - c * steps * 64;
-    return (double)rounds * ((double)steps * 1.40e-6 + 35e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
-           (rest > 0 ? 15e-6 + (double)(rest * batch) * (double)(N * K) * 2.0 / 0.9e15 : 0.0);
+    const int64_t rounds = (tiles * c + kCus - 1) / kCus, per_c = M / (128 * c) * 128;
+    const int64_t steps = (M - (c - 1) * per_c + 127) / 128 * 2;
+    return (double)rounds * ((double)steps * 1.40e-6 + 35e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12;
   };
   int64_t s = 1;
   double best = 1e30;
@@ -477,7 +486,8 @@ int wgrad_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* r
   if (env_s > 0) s = env_s;
   while (s > 1 && M / (128 * s) < 2) --s;
   const int64_t per = M / (128 * s) * 128;
-  if (per < 256 || per * N * 2 >= ((int64_t)1 << 32) || per * K * 2 >= ((int64_t)1 << 32)) return 0;
+  const int64_t last = (M - (s - 1) * per + 127) / 128 * 128;   // the last slice, with the uncovered rows, in whole tile pairs
+  if (per < 256 || last * N * 2 >= ((int64_t)1 << 32) || last * K * 2 >= ((int64_t)1 << 32)) return 0;
   if (rows_per_slice) *rows_per_slice = per;
   if (seconds) *seconds = cost(s);
   return (int)s;
@@ -500,7 +510,8 @@ extern "C" double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, i
 // `batch` + `batch2` products of one shape in one launch: product p < batch at dY + p * stride_y / H + p * stride_h, product
 // batch + q at dY2 + q * stride_y2 / H2 + q * stride_h2 (elements; rows of N / K elements, contiguous; batch2 = 0: one
 // group).  slabs [batch + batch2][slices][N][K] fp32 (written, not accumulated): slab (p, s) = sum over rows
-// [s * rows_per_slice, +rows_per_slice) of dY_p[m][n] * H_p[m][k].  Rows from slices * rows_per_slice on are the caller's.
+// [s * rows_per_slice, +rows_per_slice) of dY_p[m][n] * H_p[m][k]; the last slab also holds the rows from
+// slices * rows_per_slice to M where caiman_wgrad_tn_covers_remainder() says so (else those rows are the caller's).
 extern "C" int caiman_wgrad_tn2(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, int batch, const void* dY2,
                                 int64_t stride_y2, const void* H2, int64_t stride_h2, int batch2, float* slabs, int64_t M,
                                 int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream) {
@@ -522,16 +533,17 @@ extern "C" int caiman_wgrad_tn2(const void* dY, int64_t stride_y, const void* H,
   // the 8-phase kernel wherever the slices are pairs of its 64-row tiles (what caiman_wgrad_tn_plan hands out);
   // CAIMAN_WGRAD_KERNEL=ring: the round-3 four-stage ring kernel (A/B)
   static const bool ring = std::getenv("CAIMAN_WGRAD_KERNEL") != nullptr && std::string(std::getenv("CAIMAN_WGRAD_KERNEL")) == "ring";
-  if (!ring && rows_per_slice % 128 == 0 && rows_per_slice >= 256 && rows_per_slice * N * 2 < ((int64_t)1 << 32) &&
-      rows_per_slice * K * 2 < ((int64_t)1 << 32)) {
+  const int64_t last_rows = (M - (int64_t)(slices - 1) * rows_per_slice + 127) / 128 * 128;
+  if (!ring && rows_per_slice % 128 == 0 && rows_per_slice >= 256 && last_rows * N * 2 < ((int64_t)1 << 32) &&
+      last_rows * K * 2 < ((int64_t)1 << 32)) {
     if (dtype == CAIMAN_BF16)
       hipLaunchKernelGGL((joint_wgrad8_kernel<bf16_t>), dim3((unsigned)grid), dim3(512), 0, s, (const bf16_t*)dY, (const bf16_t*)H,
                          slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
-                         (const bf16_t*)dY2, stride_y2, (const bf16_t*)H2, stride_h2);
+                         (const bf16_t*)dY2, stride_y2, (const bf16_t*)H2, stride_h2, M);
     else
       hipLaunchKernelGGL((joint_wgrad8_kernel<f16_t>), dim3((unsigned)grid), dim3(512), 0, s, (const f16_t*)dY, (const f16_t*)H,
                          slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
-                         (const f16_t*)dY2, stride_y2, (const f16_t*)H2, stride_h2);
+                         (const f16_t*)dY2, stride_y2, (const f16_t*)H2, stride_h2, M);
     return check_launch("transposed-read weight gradient (8-phase)");
   }
   if (dtype == CAIMAN_BF16)
@@ -543,6 +555,14 @@ extern "C" int caiman_wgrad_tn2(const void* dY, int64_t stride_y, const void* H,
                        slabs, (int)N, (int)K, (int)rows_per_slice, tiles_k, n_tiles, slices, stride_y, stride_h, batch,
                        (const f16_t*)dY2, stride_y2, (const f16_t*)H2, stride_h2);
   return check_launch("transposed-read weight gradient");
+}
+// 1 when a call with this plan also sums the rows behind slices * rows_per_slice (the 8-phase kernel: they ride in the last
+// slice), 0 when they are the caller's (the round-3 ring kernel, or slices that are not pairs of 64-row tiles).
+extern "C" int caiman_wgrad_tn_covers_remainder(int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice) {
+  static const bool ring = std::getenv("CAIMAN_WGRAD_KERNEL") != nullptr && std::string(std::getenv("CAIMAN_WGRAD_KERNEL")) == "ring";
+  if (ring || slices < 1 || rows_per_slice < 256 || rows_per_slice % 128 != 0 || (int64_t)slices * rows_per_slice > M) return 0;
+  const int64_t last_rows = (M - (int64_t)(slices - 1) * rows_per_slice + 127) / 128 * 128;
+  return last_rows * N * 2 < ((int64_t)1 << 32) && last_rows * K * 2 < ((int64_t)1 << 32) ? 1 : 0;
 }
 extern "C" int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch,
                                int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype,

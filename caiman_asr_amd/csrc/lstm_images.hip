@@ -132,6 +132,26 @@ __global__ __launch_bounds__(256) void lstm_grad_deliver_kernel(DeliverBatch db)
   }
 }
 
+// h / c rows of each utterance's last valid step, every layer, one launch (rsp.py:108-130 there picks them with two
+// advanced-indexing operations per stack).  Rows are moved as 4-byte words (row bytes % 4 == 0 is checked by the caller).
+struct LastStates {
+  const char* src[2];
+  char* dst[2];
+  int64_t stride_l[2], stride_t[2];   // bytes
+  const void* lens;
+  int lens_kind, back;
+  int64_t T, B, row_bytes;
+};
+__global__ __launch_bounds__(256) void lstm_last_states_kernel(LastStates a) {
+  const int b = blockIdx.x, l = blockIdx.y, which = blockIdx.z;
+  int64_t t = (a.lens_kind == 0 ? (int64_t)static_cast<const int32_t*>(a.lens)[b] : static_cast<const int64_t*>(a.lens)[b]) - 1 - a.back;
+  if (t < 0) t += a.T;                      // Python indexing: -1 is the last step
+  t = t < 0 ? 0 : (t >= a.T ? a.T - 1 : t);   // out of range is an indexing error in torch; never read outside the tensor
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(a.src[which] + l * a.stride_l[which] + t * a.stride_t[which] + b * a.row_bytes);
+  uint32_t* d = reinterpret_cast<uint32_t*>(a.dst[which] + ((int64_t)l * a.B + b) * a.row_bytes);
+  for (int64_t i = threadIdx.x; i < a.row_bytes / 4; i += blockDim.x) d[i] = s[i];
+}
+
 }  // namespace
 }  // namespace caiman
 
@@ -188,4 +208,25 @@ extern "C" int caiman_lstm_weight_images(const caiman_lstm_images_t* layers, int
   if (dtype == CAIMAN_BF16) hipLaunchKernelGGL((lstm_images_kernel<bf16_t>), dim3((unsigned)jobs), dim3(256), 0, s, ib);
   else hipLaunchKernelGGL((lstm_images_kernel<f16_t>), dim3((unsigned)jobs), dim3(256), 0, s, ib);
   return check_launch("lstm weight images");
+}
+
+extern "C" int caiman_lstm_last_states(const void* h, const void* c, int64_t L, int64_t T, int64_t B, int64_t row_bytes,
+                                       int64_t h_stride_l, int64_t h_stride_t, int64_t c_stride_l, int64_t c_stride_t,
+                                       const void* lens, int lens_kind, int back, void* h_out, void* c_out,
+                                       caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(h && c && h_out && c_out && lens, "caiman_lstm_last_states: null pointer");
+  CAIMAN_CHECK(L >= 1 && L <= 65535 && T >= 1 && B >= 1 && row_bytes >= 4 && row_bytes % 4 == 0, "caiman_lstm_last_states: bad extents");
+  CAIMAN_CHECK(lens_kind == 0 || lens_kind == 1, "caiman_lstm_last_states: lens_kind 0 (int32) or 1 (int64)");
+  CAIMAN_CHECK(back >= 0, "caiman_lstm_last_states: negative look-back");
+  CAIMAN_CHECK(((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(h_out) |
+                 reinterpret_cast<uintptr_t>(c_out) | (uintptr_t)h_stride_l | (uintptr_t)h_stride_t | (uintptr_t)c_stride_l |
+                 (uintptr_t)c_stride_t) & 3u) == 0, "caiman_lstm_last_states: pointers and strides must be multiples of 4 bytes");
+  LastStates a;
+  a.src[0] = static_cast<const char*>(h); a.src[1] = static_cast<const char*>(c);
+  a.dst[0] = static_cast<char*>(h_out); a.dst[1] = static_cast<char*>(c_out);
+  a.stride_l[0] = h_stride_l; a.stride_t[0] = h_stride_t; a.stride_l[1] = c_stride_l; a.stride_t[1] = c_stride_t;
+  a.lens = lens; a.lens_kind = lens_kind; a.back = back; a.T = T; a.B = B; a.row_bytes = row_bytes;
+  hipLaunchKernelGGL(lstm_last_states_kernel, dim3((unsigned)B, (unsigned)L, 2u), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("lstm last states");
 }

@@ -32,37 +32,62 @@ class SpecAugment(BaseFeatures):
         self.time_masks, self.min_time, self.max_time = time_masks, min_time, max_time
         self.noise_magnitude = noise_magnitude
 
-    @torch.no_grad()
-    def mask_geometry(self, shape, x_lens, device, generator=None):
-        """-> (f0, fw, t0, tw): start and width of every frequency mask [B, freq_masks] and time mask [B, max_n] (float
-        tensors holding integers; width 0 = no mask; None where there are no masks of that kind).  All drawn on the device."""
-        B, F, T = shape
-        lens = x_lens.to(device=device, dtype=torch.float32)
+    def _time_slots(self, T):
+        """mask slots per utterance: the count itself, or room for the longest utterance's adaptive count"""
+        return int(round(T * self.time_masks)) + 1 if 0 < self.time_masks < 1.0 else int(self.time_masks)
 
-        def rnd(*size):
-            return torch.rand(*size, device=device, generator=generator)
-
+    def geometry_from_draws(self, r, lens, F, T):
+        """The reference's mask arithmetic (features.py:60-101 there) on uniform draws r [B, 2 freq_masks + 2 slots]
+        (columns: fw | f0 | tw | t0 draws), as torch operations: what the CPU path runs and what the kernel
+        (csrc/frontend.hip::specaug_geometry_kernel) is tested against."""
+        B, nf, nt = r.shape[0], self.freq_masks, self._time_slots(T)
         f0 = fw = t0 = tw = None
-        if self.freq_masks > 0:
-            fw = torch.floor(rnd(B, self.freq_masks) * (self.max_freq - self.min_freq + 1)) + self.min_freq
-            f0 = torch.floor(rnd(B, self.freq_masks) * torch.clamp(F - fw + 1, min=1))
-        # adaptive count / width per utterance
-        if 0 < self.time_masks < 1.0:
-            n_masks = torch.round(lens * self.time_masks)
-            max_n = int(round(T * self.time_masks)) + 1
-        else:
-            n_masks = torch.full((B,), float(self.time_masks), device=device)
-            max_n = int(self.time_masks)
-        if max_n > 0:
+        if nf > 0:
+            fw = torch.floor(r[:, :nf] * (self.max_freq - self.min_freq + 1)) + self.min_freq
+            f0 = torch.floor(r[:, nf:2 * nf] * torch.clamp(F - fw + 1, min=1))
+        if nt > 0:
+            # adaptive count / width per utterance
+            if 0 < self.time_masks < 1.0:
+                n_masks = torch.round(lens * self.time_masks)
+            else:
+                n_masks = torch.full((B,), float(self.time_masks), device=r.device)
             if 0 < self.max_time < 1.0:
                 max_t = torch.round(lens * self.max_time)
             else:
-                max_t = torch.full((B,), float(self.max_time), device=device)
-            w = torch.floor(rnd(B, max_n) * (max_t.unsqueeze(1) - self.min_time + 1)) + self.min_time
-            t0 = torch.floor(rnd(B, max_n) * torch.clamp(T - w + 1, min=1))
-            live = torch.arange(max_n, device=device).view(1, max_n) < n_masks.view(B, 1)
+                max_t = torch.full((B,), float(self.max_time), device=r.device)
+            w = torch.floor(r[:, 2 * nf:2 * nf + nt] * (max_t.unsqueeze(1) - self.min_time + 1)) + self.min_time
+            t0 = torch.floor(r[:, 2 * nf + nt:] * torch.clamp(T - w + 1, min=1))
+            live = torch.arange(nt, device=r.device).view(1, nt) < n_masks.view(B, 1)
             tw = torch.where(live, w, torch.zeros_like(w))
         return f0, fw, t0, tw
+
+    @torch.no_grad()
+    def mask_geometry(self, shape, x_lens, device, generator=None):
+        """-> (f0, fw, t0, tw): start and width of every frequency mask [B, freq_masks] and time mask [B, slots] (float
+        tensors holding integers; width 0 = no mask; None where there are no masks of that kind).  One draw of uniforms
+        and, on the GPU, one kernel (caiman_specaug_geometry) -- no host round trip, no chain of small torch kernels."""
+        B, F, T = shape
+        device = torch.device(device)
+        nf, nt = self.freq_masks, self._time_slots(T)
+        if nf + nt == 0:
+            return None, None, None, None
+        r = torch.rand(B, 2 * nf + 2 * nt, device=device, generator=generator)
+        if device.type != "cuda":
+            return self.geometry_from_draws(r, x_lens.to(device=device, dtype=torch.float32), F, T)
+        from caiman_asr_amd import _lib
+
+        lens = x_lens.to(device)
+        kind = {torch.int32: 0, torch.int64: 1, torch.float32: 2}.get(lens.dtype)
+        if kind is None:
+            lens, kind = lens.float(), 2
+        lens = lens.contiguous()
+        out = torch.empty(B * (2 * nf + 2 * nt), dtype=torch.float32, device=device)
+        _lib.check(_lib.lib().caiman_specaug_geometry(
+            _lib.ptr(r), _lib.ptr(lens), kind, B, F, T, nf, float(self.min_freq), float(self.max_freq - self.min_freq + 1),
+            float(self.time_masks), nt, float(self.min_time), float(self.max_time), _lib.ptr(out), _lib.stream()))
+        fw, f0, tw, t0 = torch.split(out, [B * nf, B * nf, B * nt, B * nt])
+        two = lambda t, n: t.view(B, n) if n > 0 else None
+        return two(f0, nf), two(fw, nf), two(t0, nt), two(tw, nt)
 
     @torch.no_grad()
     def make_mask(self, shape, x_lens, device, generator=None):

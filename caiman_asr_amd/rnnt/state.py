@@ -34,14 +34,42 @@ class BatchChunks:
         self.parts, self.bounds = list(parts), list(bounds)
 
 
+def _rows_selectable(t):
+    """[L, T, B, H] with the rows of a step contiguous and 4-byte granular: what the gather kernel takes"""
+    return (t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3]
+            and (t.shape[3] * t.element_size()) % 4 == 0 and (t.stride(0) * t.element_size()) % 4 == 0
+            and (t.stride(1) * t.element_size()) % 4 == 0 and t.data_ptr() % 4 == 0 and t.shape[0] <= 65535
+            and t.shape[1] >= 1 and t.shape[2] >= 1)
+
+
 def get_last_nonpadded_states(all_hid, lens, how_far_back: int = 0):
     """all_hid: (h, c) each [L, T, B, H]; pick step lens[b]-1-how_far_back per utterance."""
     if isinstance(all_hid, BatchChunks):
         got = [get_last_nonpadded_states(part, lens[a:b], how_far_back) for part, (a, b) in zip(all_hid.parts, all_hid.bounds)]
         return torch.cat([g[0] for g in got], dim=1), torch.cat([g[1] for g in got], dim=1)
+    h, c = all_hid
+    if h.is_cuda and _rows_selectable(h) and _rows_selectable(c) and h.shape == c.shape and h.dtype == c.dtype:
+        # one launch for both tensors and every layer (include/caiman_rnnt.h caiman_lstm_last_states) instead of the
+        # index arithmetic + two gathers below (9 small kernels per stack).  The result is outside autograd: a carried
+        # state is detached where it is consumed (training/lib/src/rnnt_ext/custom_lstm/lstm.py:376-377 there,
+        # CustomLSTM.forward here), so no gradient ever flows through this selection.
+        from caiman_asr_amd import _lib
+
+        h, c = h.detach(), c.detach()
+        L, T, B, H = h.shape
+        lens_d = lens.to(h.device)
+        if lens_d.dtype not in (torch.int32, torch.int64):
+            lens_d = lens_d.long()
+        lens_d = lens_d.contiguous()
+        es = h.element_size()
+        h_out, c_out = h.new_empty((L, B, H)), c.new_empty((L, B, H))
+        _lib.check(_lib.lib().caiman_lstm_last_states(
+            _lib.ptr(h), _lib.ptr(c), L, T, B, H * es, h.stride(0) * es, h.stride(1) * es, c.stride(0) * es, c.stride(1) * es,
+            _lib.ptr(lens_d), int(lens_d.dtype == torch.int64), how_far_back, _lib.ptr(h_out), _lib.ptr(c_out), _lib.stream()))
+        return h_out, c_out
     idx = (lens.long() - 1 - how_far_back)
     cols = torch.arange(len(lens), device=idx.device)
-    return all_hid[0][:, idx, cols, :], all_hid[1][:, idx, cols, :]
+    return h[:, idx, cols, :], c[:, idx, cols, :]
 
 
 def maybe_get_last_nonpadded(all_hid, lens):

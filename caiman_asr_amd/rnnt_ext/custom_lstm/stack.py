@@ -36,6 +36,9 @@ def _chunk(L, T=None):
         return CHUNK_SHORT
     return CHUNK_DEEP if L >= 4 else CHUNK
 IMAGES = int(__import__("os").environ.get("CAIMAN_LSTM_IMAGES", "1")) != 0   # csrc/lstm_images.hip: one launch for all weight images
+# parameter gradients are ADDED into `param.grad` by one kernel per layer (un-permute + accumulate; autograd gets None), as
+# in encoder_pipe.py; 0: returned to autograd after an un-permute copy each
+EARLY_WGRAD = int(__import__("os").environ.get("CAIMAN_EARLY_WGRAD", "1")) != 0
 INTERLEAVED = 1  # gate layout used INSIDE the pipeline: [.., H, 4] (see include/caiman_rnnt.h)
 RINGS_ZEROED = 2  # caiman_lstm_prepare(gate_layout | RINGS_ZEROED): the caller has cleared ring / dC itself (one memset for all layers)
 
@@ -105,6 +108,9 @@ class StackFunction(torch.autograd.Function):
         dev = x.device
         lib = _lib.lib()
         H = Rs[0].shape[1]
+        # an output nobody differentiates (all_h when the states are only carried, y_top never) arrives as None in backward,
+        # not as a tensor of zeros: the general path there (explicit dropout factors, one add per chunk) is for real gradients
+        ctx.set_materialize_grads(False)
         # the pipeline keeps gates / dG unit-major ([.., H, 4]): permute the ROWS of W_ih and of the biases once
         # per call (R keeps its layout: the tiling kernels absorb the permutation)
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
@@ -267,7 +273,8 @@ class StackFunction(torch.autograd.Function):
                     tm.units = 1
                     tm.nbytes -= sum(s_.nsteps - 1 for s_ in slots) * 4 * H * H * G.element_size()
 
-        def weight_grads(l):
+        def weight_grads(l, unperm=True):
+            """[dW, dR, db, db] of layer l; unperm=False: rows left in the pipeline's [unit][gate] order, contiguous"""
             dg = dG[l].view(T * B, 4 * H)
             if l == 0:
                 xin = x.detach().flatten(0, 1).to(dt)
@@ -276,12 +283,37 @@ class StackFunction(torch.autograd.Function):
             # parameter gradients leave as fp32 products (a 16-bit library output would round every element once more:
             # up to 4e-3 of the tensor's range, profiles/r04_bf16_residual.md)
             f32 = dict(out_dtype=torch.float32) if dg.dtype in (torch.float16, torch.bfloat16) else {}
-            dB = _unperm_rows(dbias[l] if fused_db else dg.sum(0, dtype=torch.float32), H)
-            return [_unperm_rows(torch.mm(dg.t(), xin, **f32), H),
-                    _unperm_rows(torch.mm(dg.t(), Y[l, :-1].reshape(T * B, H), **f32), H), dB, dB]
+            fix = (lambda g_: _unperm_rows(g_, H)) if unperm else (lambda g_: g_)
+            dB = fix(dbias[l] if fused_db else dg.sum(0, dtype=torch.float32))
+            return [fix(torch.mm(dg.t(), xin, **f32)), fix(torch.mm(dg.t(), Y[l, :-1].reshape(T * B, H), **f32)), dB, dB]
 
         dX = torch.matmul(dG[0].view(T * B, 4 * H), Wp[0].t()).view(T, B, -1) if need_dx else None
-        grads = []
+        grads, pending = [], []
+
+        def flush():
+            """up to two layers (8 parameters) per launch: un-permute the gate rows and add into `.grad`"""
+            if not pending:
+                return
+            items = (_lib.GradItem * len(pending))(*[
+                _lib.GradItem(g_.data_ptr(), p_.grad.data_ptr(), H, p_.shape[1] if p_.dim() == 2 else 1,
+                              int(g_.dtype == torch.float32), 0) for p_, g_ in pending])
+            _lib.check(lib.caiman_lstm_grad_deliver(ctypes.cast(items, ctypes.c_void_p), len(pending), tag, st))
+            for p_, _ in pending:
+                overlap.notify_grad_ready(p_)
+            pending.clear()
+
         for l in range(L):
-            grads += weight_grads(l)
+            ps = ctx.params[4 * l:4 * l + 4]
+            if (EARLY_WGRAD and IMAGES and dt in (torch.float16, torch.bfloat16)
+                    and all(p_.requires_grad and p_.dtype == torch.float32 and p_.is_contiguous() for p_ in ps)):
+                for p_ in ps:
+                    if p_.grad is None:
+                        p_.grad = torch.zeros_like(p_)
+                pending += list(zip(ps, weight_grads(l, unperm=False)))   # the sources stay alive until the launch
+                if len(pending) == 8:
+                    flush()
+                grads += [None] * 4
+            else:
+                grads += weight_grads(l)
+        flush()
         return (dX, None, None, None, None, None, *grads)

@@ -185,7 +185,7 @@ def wgrad_tn(dy3, x3, only_if_faster=False, second=None):
                                        _lib.stream()))
     dw = slabs.sum(1) if slices > 1 else slabs[:, 0]
     done = slices * per.value
-    if done < M:
+    if done < M and not lib.caiman_wgrad_tn_covers_remainder(M, N, K, slices, per.value):   # else: they rode in the last slice
         dw[:P] += torch.bmm(dy3[:, done:].transpose(1, 2), x3[:, done:], out_dtype=torch.float32)
         if P2:
             dw[P:] += torch.bmm(dyb[:, done:].transpose(1, 2), xb[:, done:], out_dtype=torch.float32)

@@ -344,7 +344,9 @@ int caiman_joint_fc_forward(const void* A, const void* W, const void* bias, void
  * `slices` consecutive row ranges of `rows_per_slice` rows (a multiple of 128 from caiman_joint_fc_wgrad_plan: pairs of the
  * 8-phase kernel's 64-row tiles; multiples of 32 >= 96 are still accepted and run on the round-3 ring kernel; 0 slices =
  * shape not supported: N, K % 256 == 0, M >= 256, bf16 / f16); slabs [slices][N][K] fp32 receives one partial product per slice
- * (written, not accumulated).  The caller adds the slabs in order, plus the product of the rows past slices * rows_per_slice. */
+ * (written, not accumulated).  The caller adds the slabs in order.  The rows past slices * rows_per_slice (fewer than 128 per
+ * slice) are summed into the LAST slab by the 8-phase kernel (its operand descriptors end with row M - 1: the rows of the
+ * last tile pair past the end read as zeros); caiman_wgrad_tn_covers_remainder() = 0 (ring kernel) leaves them to the caller. */
 int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice);
 int caiman_joint_fc_wgrad(const void* dY, const void* H, float* slabs, int64_t M, int64_t N, int64_t K, int slices,
                           int64_t rows_per_slice, int dtype, caiman_stream_t stream);
@@ -355,6 +357,7 @@ int caiman_wgrad_tn_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, 
 /* microseconds the plan's cost model expects (round quantisation over 256 CUs, per-workgroup fixed cost, slabs); < 0: shape
  * not supported.  For callers that keep the kernel to the calls where it is expected to beat their library product. */
 double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, int batch, int dtype);
+int caiman_wgrad_tn_covers_remainder(int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice);
 int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch, int64_t M,
                     int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream);
 /* two strided groups of products of one shape in one launch (the layers' dR and dW share the gradients and the shape, not the
@@ -446,6 +449,27 @@ int caiman_logmel_forward(const float* audio, const int32_t* audio_len, int64_t 
 int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int nmel, int64_t T,
                          const float* ds_mean, const float* ds_std, float ratio,
                          caiman_stream_t stream);
+
+/* The (h, c) rows of every utterance's last valid step, all layers of a stack, in one launch — replaces the two
+ * advanced-indexing selections of training/caiman_asr_train/train_utils/rsp.py:108-130 (`get_last_nonpadded_states`; with
+ * back = 1 the prediction network's next-to-last state, rsp.py:132-205).  h, c: [L][T][B] rows of row_bytes bytes each
+ * (rows of a step contiguous; layer and step strides in bytes, so views that skip the initial-state row qualify);  lens [B]
+ * (lens_kind 0: int32, 1: int64);  step picked = lens[b] - 1 - back, a negative value counting from the end as in Python
+ * indexing;  h_out, c_out: [L][B] rows, contiguous.  B <= 2^31 - 1, L <= 65535. */
+int caiman_lstm_last_states(const void* h, const void* c, int64_t L, int64_t T, int64_t B, int64_t row_bytes,
+                            int64_t h_stride_l, int64_t h_stride_t, int64_t c_stride_l, int64_t c_stride_t,
+                            const void* lens, int lens_kind, int back, void* h_out, void* c_out, caiman_stream_t stream);
+
+/* SpecAugment mask geometry in one launch — the arithmetic of training/caiman_asr_train/data/features.py:60-101 (widths
+ * U[min, max], starts U[0, extent - width], adaptive counts / widths as fractions of the utterance length) applied to
+ * uniform draws the caller made: rnd [B][2 nf + 2 nt] in [0, 1), columns = draws for fw | f0 | tw | t0;  lens [B] frames per
+ * utterance (lens_kind 0: int32, 1: int64, 2: float);  freq_span = max_freq - min_freq + 1;  time_masks: a count (>= 1,
+ * nt = that count) or a fraction of the length in (0, 1) (nt = round(T * fraction) + 1 slots, the ones past an utterance's
+ * count get width 0);  max_time likewise a width or a fraction.  out: fw [B][nf], f0 [B][nf], tw [B][nt], t0 [B][nt] f32,
+ * one after the other — the arrays caiman_specaug_splice takes. */
+int caiman_specaug_geometry(const float* rnd, const void* lens, int lens_kind, int64_t B, int64_t F, int64_t T, int nf,
+                            float min_freq, float freq_span, float time_masks, int nt, float min_time, float max_time,
+                            float* out, caiman_stream_t stream);
 
 /* SpecAugment masks applied + frame splicing + PermuteAudio in one pass — replaces the tail of the reference's feature
  * processors (training/caiman_asr_train/data/features.py:34-115 `SpecAugment.calculate_features`' masked_fill, :118-139

@@ -137,7 +137,7 @@ def test_model_step_with_the_handwritten_joint_projection_equals_the_library_pat
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [
     (512, 256, 256),          # one tile, the shortest slice (4 stages of 32 rows per slice at most)
-    (5000, 512, 768),         # rows past the slices (5000 is not a multiple of 128): the caller's remainder product
+    (5000, 512, 768),         # rows past the slices (5000 is not a multiple of 128): they ride in the last slice, zero-padded by the descriptor
     (20011, 8704, 768),       # the joint projection's own N and K: 102 tiles x 5 slices
     (9000, 2048, 1024),       # K = 1024 (large-196M joint_n_hid)
 ])

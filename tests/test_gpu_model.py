@@ -433,3 +433,25 @@ def test_grouped_projection_and_fused_weight_images_match_the_library_path(T1, f
     assert len(g0) == 20
     for n in g0:
         assert torch.allclose(g0[n], g1[n], atol=1.5 * tol * float(g0[n].abs().max()) + 1e-6, rtol=0), n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("back", [0, 1])
+def test_last_state_gather_kernel_equals_advanced_indexing(dtype, back):
+    """caiman_lstm_last_states (one launch per stack) against the reference's selection (rsp.py:108-130: two advanced-indexing
+    gathers): same rows, including views that skip the initial-state row, int32 / int64 lengths and the wrap of index -1."""
+    from caiman_asr_amd.rnnt.state import get_last_nonpadded_states
+
+    L, T, B, H = 3, 17, 9, 64
+    g = torch.Generator().manual_seed(L * T + back)
+    full_h = torch.randn(L, T + 1, B, H, generator=g).to(dtype).to(DEV)
+    full_c = torch.randn(L, T + 1, B, H, generator=g).to(dtype).to(DEV)
+    h, c = full_h[:, 1:], full_c[:, 1:]
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0], lens[1] = T, 1                      # lens 1 with back = 1 selects index -1 = the last step
+    for lens_d in (lens.to(DEV), lens.int().to(DEV), lens):
+        got = get_last_nonpadded_states((h, c), lens_d, back)
+        idx = lens.long().to(DEV) - 1 - back
+        cols = torch.arange(B, device=DEV)
+        assert torch.equal(got[0], h[:, idx, cols, :]) and torch.equal(got[1], c[:, idx, cols, :])
+        assert got[0].is_contiguous() and got[0].shape == (L, B, H)

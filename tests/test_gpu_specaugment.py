@@ -101,3 +101,34 @@ def test_fused_augment_splice_permute_equals_the_three_modules(B, F, T, stack, s
     assert torch.equal(lens_got.cpu(), lens_ref.cpu())
     if with_spec:
         assert (got == 0).float().mean() > 0.01      # masks were applied
+
+
+@pytest.mark.parametrize("kw", [
+    dict(freq_masks=2, min_freq=0, max_freq=20, time_masks=10, min_time=0, max_time=0.03),      # the training configuration
+    dict(freq_masks=2, min_freq=3, max_freq=27, time_masks=0.04, min_time=0, max_time=0.05),    # adaptive count and width
+    dict(freq_masks=0, time_masks=3, min_time=1, max_time=40),                                  # absolute widths, no bands
+    dict(freq_masks=3, min_freq=0, max_freq=80, time_masks=0),                                  # bands as wide as the axis
+])
+@pytest.mark.parametrize("lens_dtype", [torch.int32, torch.int64, torch.float32])
+def test_mask_geometry_kernel_equals_the_torch_arithmetic_on_the_same_draws(kw, lens_dtype):
+    """caiman_specaug_geometry (one launch) against SpecAugment.geometry_from_draws (the reference's arithmetic,
+    features.py:60-101, as a chain of torch operations) on the same uniform draws: every start and width bit for bit."""
+    from caiman_asr_amd.data.features import SpecAugment
+
+    B, F, T = 37, 80, 1203
+    spec = SpecAugment(**kw)
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0], lens[1] = T, 1
+    lens_d = lens.to(DEV).to(lens_dtype)
+    torch.manual_seed(77)
+    got = spec.mask_geometry((B, F, T), lens_d, DEV)
+    torch.manual_seed(77)
+    r = torch.rand(B, 2 * spec.freq_masks + 2 * spec._time_slots(T), device=DEV)
+    ref = spec.geometry_from_draws(r, lens_d.float(), F, T)
+    for name, a, b in zip(("f0", "fw", "t0", "tw"), got, ref):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert a.shape == b.shape and a.is_contiguous() and torch.equal(a, b), name
+    if got[2] is not None:   # starts leave room for the mask inside the padded length
+        assert bool(((got[2] + got[3]) <= T).all()) and bool((got[2] >= 0).all())
