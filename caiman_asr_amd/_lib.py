@@ -109,7 +109,7 @@ class LstmImages(ctypes.Structure):
 class GradItem(ctypes.Structure):
     """caiman_lstm_grad_item_t (include/caiman_rnnt.h)."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("H", ctypes.c_int32), ("cols", ctypes.c_int32),
-                ("src_fp32", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("src_fp32", ctypes.c_int32), ("slabs", ctypes.c_int32)]
 
 
 class BeamConfig(ctypes.Structure):
@@ -153,6 +153,7 @@ _SIGS = {
     "caiman_joint_fc_wgrad": ([P, P, P, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_wgrad_tn_plan": ([I64, I64, I64, I32, I32, P], ctypes.c_int),
     "caiman_wgrad_tn_estimate_us": ([I64, I64, I64, I32, I32], ctypes.c_double),
+    "caiman_slab_accumulate": ([P, I32, I64, P, P], ctypes.c_int),
     "caiman_wgrad_tn_covers_remainder": ([I64, I64, I64, I32, I64], ctypes.c_int),
     "caiman_wgrad_tn": ([P, I64, P, I64, P, I32, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
     "caiman_wgrad_tn2": ([P, I64, P, I64, I32, P, I64, P, I64, I32, P, I64, I64, I64, I32, I64, I32, P], ctypes.c_int),
@@ -178,6 +179,7 @@ _SIGS = {
     "caiman_logmel_forward": ([P, P, I64, I64, I32, I32, I32, I32, I32, F32, F32, ctypes.c_uint64, F32, P, P, P, P, P, P,
                                P, P, I64, P], ctypes.c_int),
     "caiman_mel_normalize": ([P, P, I64, I32, I64, P, P, F32, P], ctypes.c_int),
+    "caiman_embedding_grad": ([P, I64, P, I32, I64, I64, P, P], ctypes.c_int),
     "caiman_lstm_last_states": ([P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, I32, I32, P, P, P], ctypes.c_int),
     "caiman_specaug_geometry": ([P, P, I32, I64, I64, I64, I32, F32, F32, F32, I32, F32, F32, P, P], ctypes.c_int),
     "caiman_specaug_splice": ([P, I64, I64, I64, P, P, I32, P, P, I32, I32, I32, I64, P, P], ctypes.c_int),

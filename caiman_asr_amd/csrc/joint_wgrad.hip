@@ -571,6 +571,35 @@ extern "C" int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, 
                           dtype, stream);
 }
 
+// dst[i] += slabs[0][i] + slabs[1][i] + ... (slabs of n floats, one behind the other, added in order): the partial products of
+// a sliced weight gradient straight into the parameter's fp32 `.grad`, one pass instead of a reduction and an accumulate.
+namespace caiman {
+namespace {
+__global__ __launch_bounds__(256) void slab_accumulate_kernel(const float* __restrict__ slabs, int slices, int64_t n4,
+                                                              float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<const float4*>(slabs)[i];
+  for (int s = 1; s < slices; ++s) {
+    const float4 w = reinterpret_cast<const float4*>(slabs)[(int64_t)s * n4 + i];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  float4 a = reinterpret_cast<float4*>(dst)[i];
+  a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  reinterpret_cast<float4*>(dst)[i] = a;
+}
+}  // namespace
+}  // namespace caiman
+extern "C" int caiman_slab_accumulate(const float* slabs, int slices, int64_t n, float* dst, caiman_stream_t stream) {
+  using namespace caiman;
+  CAIMAN_CHECK(slabs && dst && slices >= 1 && slices <= 4096 && n >= 4 && n % 4 == 0, "slab_accumulate: 1 .. 4096 slabs of n %% 4 == 0 floats");
+  CAIMAN_CHECK(((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0, "slab_accumulate: 16-byte aligned pointers");
+  CAIMAN_CHECK((n / 4 + 255) / 256 < ((int64_t)1 << 31), "slab_accumulate: too many elements");
+  hipLaunchKernelGGL(slab_accumulate_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     slabs, slices, n / 4, dst);
+  return check_launch("slab accumulate");
+}
+
 // The joint projection's instance (one product): include/caiman_rnnt.h.
 extern "C" int caiman_joint_fc_wgrad_plan(int64_t M, int64_t N, int64_t K, int dtype, int64_t* rows_per_slice) {
   return M < 512 ? 0 : caiman_wgrad_tn_plan(M, N, K, 1, dtype, rows_per_slice);

@@ -115,7 +115,13 @@ __global__ __launch_bounds__(256) void lstm_grad_deliver_kernel(DeliverBatch db)
     const int64_t d = (int64_t)((r & 3) * H + (r >> 2)) * cols + c;
     float4 a = *reinterpret_cast<const float4*>(dst + d);
     if (I.src_fp32) {
-      const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(I.src) + (int64_t)r * cols + c);
+      // partial products of the weight-gradient GEMM (slabs of 4H x cols floats, one behind the other): summed in order here
+      const float* sp = static_cast<const float*>(I.src) + (int64_t)r * cols + c;
+      float4 v = *reinterpret_cast<const float4*>(sp);
+      for (int sl = 1; sl < I.slabs; ++sl) {
+        const float4 w = *reinterpret_cast<const float4*>(sp + (int64_t)sl * 4 * H * cols);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     } else {
       using v4 = __attribute__((ext_vector_type(4))) T;
@@ -128,7 +134,10 @@ __global__ __launch_bounds__(256) void lstm_grad_deliver_kernel(DeliverBatch db)
     if (i >= (int64_t)4 * H * cols) return;
     const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
     const int64_t d = (int64_t)((r & 3) * H + (r >> 2)) * cols + c;
-    dst[d] += I.src_fp32 ? static_cast<const float*>(I.src)[i] : static_cast<float>(static_cast<const T*>(I.src)[i]);
+    float v = I.src_fp32 ? static_cast<const float*>(I.src)[i] : static_cast<float>(static_cast<const T*>(I.src)[i]);
+    if (I.src_fp32)
+      for (int sl = 1; sl < I.slabs; ++sl) v += static_cast<const float*>(I.src)[(int64_t)sl * 4 * H * cols + i];
+    dst[d] += v;
   }
 }
 
@@ -165,6 +174,7 @@ extern "C" int caiman_lstm_grad_deliver(const caiman_lstm_grad_item_t* items, in
   for (int i = 0; i < n_items; ++i) {
     const caiman_lstm_grad_item_t& I = items[i];
     CAIMAN_CHECK(I.src && I.dst && I.H >= 1 && I.cols >= 1, "caiman_lstm_grad_deliver: item %d: null pointer or empty extent", i);
+    CAIMAN_CHECK(I.slabs >= 0 && I.slabs <= 64 && (I.slabs <= 1 || I.src_fp32), "caiman_lstm_grad_deliver: item %d: 0 .. 64 slabs, fp32 sources only", i);
     CAIMAN_CHECK(I.cols % 4 != 0 || (((reinterpret_cast<uintptr_t>(I.dst) & 15u) == 0) &&
                                      ((reinterpret_cast<uintptr_t>(I.src) & (I.src_fp32 ? 15u : 7u)) == 0)),
                  "caiman_lstm_grad_deliver: item %d: misaligned pointer", i);

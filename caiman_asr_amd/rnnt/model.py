@@ -107,7 +107,9 @@ class RNNT(nn.Module):
     def _enc_pred_one_pipeline(self, x, x_lens, y, y_lens, pred_net_state, enc_state):
         """Encoder and prediction network in the same LSTM launches (encoder_pipe.py); None if not covered."""
         y = label_collate(y)
-        emb = self.prediction["embed"](y)                       # predict(): embedding, SOS row in front
+        from caiman_asr_amd.train_utils.overlap import embedding
+
+        emb = embedding(self.prediction["embed"], y)            # predict(): embedding, SOS row in front
         Bn, _, E = emb.shape
         if pred_net_state is None:
             start = torch.zeros((Bn, 1, E), device=emb.device, dtype=emb.dtype)
@@ -254,7 +256,9 @@ class RNNT(nn.Module):
     def predict(self, y, pred_state=None, add_sos: bool = True, special_sos=None):
         """y [B,U] (or None for a single zero-embedding step) -> g [B,U+1,Hj], (h,c), all states."""
         if y is not None:
-            y = self.prediction["embed"](y)
+            from caiman_asr_amd.train_utils.overlap import embedding
+
+            y = embedding(self.prediction["embed"], y)    # the module's lookup; on the GPU the table's gradient by one kernel
         else:
             B = 1 if pred_state is None else pred_state[0].size(1)
             y = torch.zeros((B, 1, self.pred_n_hid), device=self.joint_enc.weight.device,

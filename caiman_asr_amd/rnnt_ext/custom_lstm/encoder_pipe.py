@@ -554,9 +554,14 @@ class EncoderPipeFunction(torch.autograd.Function):
 
         # post layers have identical shapes: their recurrent-weight gradients (all Lb), their input-weight gradients
         # (layers 1..Lb-1) and all bias gradients are three batched calls instead of 3 * Lb
+        # the delivery kernel adds the weight-gradient kernel's partial products (slabs) up on its way into `.grad`: no
+        # separate reduction pass.  Only when every layer's gradients leave through it (`direct`, fp32 parameters).
+        raw = (direct and IMAGES and all(p_.requires_grad and p_.dtype == torch.float32 and p_.is_contiguous() for p_ in ctx.params))
+
         def tn(dg3, x3):
-            """dg3 [P, rows, 4H]^T . x3 [P, rows, K] -> [P, 4H, K]: the hand-written kernel where it applies, else the library"""
-            out = overlap.wgrad_tn(dg3, x3, only_if_faster=True) if WGRAD_TN else None
+            """dg3 [P, rows, 4H]^T . x3 [P, rows, K] -> [P, 4H, K] (or the slabs [P, slices, 4H, K] with `raw`): the
+            hand-written kernel where it applies, else the library"""
+            out = overlap.wgrad_tn(dg3, x3, only_if_faster=True, raw=raw) if WGRAD_TN else None
             return out if out is not None else torch.bmm(dg3.transpose(1, 2), x3, out_dtype=torch.float32)   # fp32 products, like the kernel's
 
         def rows3(t, first, count, skip, T):
@@ -582,7 +587,7 @@ class EncoderPipeFunction(torch.autograd.Function):
                     e2 = min(e_r, lib_us(Lb)) if e_r > 0 else lib_us(Lb)
                     e2 += min(e_w, lib_us(Lb - 1)) if e_w > 0 else lib_us(Lb - 1)
                     if e_both < e2:
-                        both = overlap.wgrad_tn(dgb, rows3(Yb, 0, Lb, 0, T2), second=(dgb[1:], xin))
+                        both = overlap.wgrad_tn(dgb, rows3(Yb, 0, Lb, 0, T2), second=(dgb[1:], xin), raw=raw)
             if both is not None:
                 post_R, post_W = both[:Lb], both[Lb:]
             else:
@@ -600,7 +605,7 @@ class EncoderPipeFunction(torch.autograd.Function):
             if e_all > 0 and e_all < (2 * La - 1) * (min(e_one, lib_one) if e_one > 0 else lib_one):
                 dga = dGa.view(La, T1 * B, 4 * H)
                 xin_a = rows3(YMa, 0, La - 1, 0, T1) if pl[0] > 0.0 else rows3(Ya, 0, La - 1, 1, T1)
-                got = overlap.wgrad_tn(dga, rows3(Ya, 0, La, 0, T1), second=(dga[1:], xin_a))
+                got = overlap.wgrad_tn(dga, rows3(Ya, 0, La, 0, T1), second=(dga[1:], xin_a), raw=raw)
                 if got is not None:
                     pre_R, pre_W = got[:La], got[La:]
         per_layer = [None] * L
@@ -628,15 +633,17 @@ class EncoderPipeFunction(torch.autograd.Function):
                     for p_ in ps:
                         if p_.grad is None:
                             p_.grad = torch.zeros_like(p_)
+                    # a 3-D weight gradient is a stack of slabs (wgrad_tn(raw=True)): the kernel sums them
                     items = (_lib.GradItem * 4)(*[
                         _lib.GradItem(g_.data_ptr(), p_.grad.data_ptr(), hl, p_.shape[1] if p_.dim() == 2 else 1,
-                                      int(g_.dtype == torch.float32), 0) for p_, g_ in zip(ps, g4)])
+                                      int(g_.dtype == torch.float32), g_.shape[0] if g_.dim() == 3 else 1)
+                        for p_, g_ in zip(ps, g4)])
                     _lib.check(lib.caiman_lstm_grad_deliver(ctypes.cast(items, ctypes.c_void_p), 4, tag, st))
                     for p_ in ps:
                         overlap.notify_grad_ready(p_)
                 else:
                     for p_, g_ in zip(ps, g4):
-                        deliver(p_, g_, hl)
+                        deliver(p_, g_.sum(0) if (g_.dim() == 3 and p_.dim() == 2) else g_, hl)
                 g4 = [None] * 4
             else:
                 g4 = [_unperm_rows(g_, hl) for g_ in g4]

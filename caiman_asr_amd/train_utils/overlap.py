@@ -143,13 +143,15 @@ def wgrad_tn_estimate_us(M, N, K, P, dtype):
     return _lib.lib().caiman_wgrad_tn_estimate_us(M, N, K, P, _lib.dtype_tag(dtype))
 
 
-def wgrad_tn(dy3, x3, only_if_faster=False, second=None):
+def wgrad_tn(dy3, x3, only_if_faster=False, second=None, raw=False):
     """dy3 [P, M, N]^T . x3 [P, M, K] per p -> [P, N, K] fp32 through caiman_wgrad_tn (csrc/joint_wgrad.hip: slices of M into
     fp32 slabs, added in order, plus the library product of the few rows the slices do not cover), or None when the shapes or
     strides are outside the kernel (rows must be contiguous, the P operands a constant stride apart) -- or, with
     `only_if_faster`, when the kernel's own cost model expects the library to be quicker (short reductions whose tile
     count fills the last round of 256 workgroups badly).  `second` = (dy3b, x3b): a second strided group of products of the
-    SAME shape in the same launch; the result then holds its products behind the first group's."""
+    SAME shape in the same launch; the result then holds its products behind the first group's.  `raw`: the slabs themselves
+    [P, slices, N, K] for a consumer that adds them up on its way (caiman_lstm_grad_deliver) -- only when the kernel has
+    covered every row; otherwise the summed [P, N, K] as usual (tell them apart by the number of dimensions)."""
     import ctypes
 
     from caiman_asr_amd import _lib
@@ -183,8 +185,10 @@ def wgrad_tn(dy3, x3, only_if_faster=False, second=None):
     else:
         _lib.check(lib.caiman_wgrad_tn(_lib.ptr(dy3), sy, _lib.ptr(x3), sx, _lib.ptr(slabs), P, M, N, K, slices, per.value, tag,
                                        _lib.stream()))
-    dw = slabs.sum(1) if slices > 1 else slabs[:, 0]
     done = slices * per.value
+    if raw and (done == M or lib.caiman_wgrad_tn_covers_remainder(M, N, K, slices, per.value)):
+        return slabs
+    dw = slabs.sum(1) if slices > 1 else slabs[:, 0]
     if done < M and not lib.caiman_wgrad_tn_covers_remainder(M, N, K, slices, per.value):   # else: they rode in the last slice
         dw[:P] += torch.bmm(dy3[:, done:].transpose(1, 2), x3[:, done:], out_dtype=torch.float32)
         if P2:
@@ -192,14 +196,15 @@ def wgrad_tn(dy3, x3, only_if_faster=False, second=None):
     return dw
 
 
-def _joint_wgrad(dy2, x2):
-    """The joint projection's instance: dy2 [M, N]^T . x2 [M, K] -> [N, K] fp32, or None (shape outside the kernel)."""
+def _joint_wgrad(dy2, x2, raw=False):
+    """The joint projection's instance: dy2 [M, N]^T . x2 [M, K] -> [N, K] fp32 (`raw`: possibly the slabs [slices, N, K],
+    see wgrad_tn), or None (shape outside the kernel)."""
     if dy2.shape[0] < 512:
         return None
     from caiman_asr_amd import _lib
 
     with _lib.timed("joint_gemm_dw", 1, 2 * dy2.shape[0] * dy2.shape[1] * x2.shape[1]):
-        out = wgrad_tn(dy2.unsqueeze(0), x2.unsqueeze(0))
+        out = wgrad_tn(dy2.unsqueeze(0), x2.unsqueeze(0), raw=raw)
     return None if out is None else out[0]
 
 
@@ -213,33 +218,54 @@ class _LinearTransposedBackward(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         from caiman_asr_amd.rnnt_ext.transducer.loss import clear_row_lse, offer_row_lse
 
-        ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         clear_row_lse()            # a projection that never reached a loss must not leave its normalisers behind
         if JOINT_GEMM != "0" and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             x2 = x.reshape(-1, x.shape[-1])
-            out = _joint_gemm(x2 if x2.is_contiguous() else x2.contiguous(), weight.to(x.dtype).contiguous(),
+            w16 = weight.to(x.dtype).contiguous()
+            ctx.save_for_backward(x, w16)      # the backward pass transposes this 16-bit image instead of casting again
+            out = _joint_gemm(x2 if x2.is_contiguous() else x2.contiguous(), w16,
                               None if bias is None else bias.to(x.dtype).contiguous(), want_lse=True)
             if out is not None:
                 c, lse = out
                 c = c.view(*x.shape[:-1], weight.shape[0])
                 offer_row_lse(c, lse)      # the loss picks the normalisers up instead of reading the logits again
                 return c
+        else:
+            ctx.save_for_backward(x, weight)
         return F.linear(x, weight, bias)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, w_saved = ctx.saved_tensors           # w_saved: the 16-bit image of the weight where the forward made one
+        weight, _bias = ctx.params
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight.to(dy2.dtype).t().contiguous()           # [K, N]
+            wt = w_saved.to(dy2.dtype).t().contiguous()           # [K, N]
             out = _joint_gemm(dy2 if dy2.is_contiguous() else dy2.contiguous(), wt, None, want_lse=False) \
                 if JOINT_GEMM == "1" else None
             dx = (out[0] if out is not None else torch.mm(dy2, wt.t())).view(*dy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = _weight_gradient(dy2, x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(weight.dtype)
+            x2 = x.reshape(-1, x.shape[-1]).to(dy2.dtype)
+            slabs = None
+            if (DIRECT_GRADS and JOINT_WGRAD and weight.dtype == torch.float32 and weight.is_contiguous() and dy2.is_cuda
+                    and dy2.dtype in (torch.float16, torch.bfloat16) and dy2.shape[0] >= 4096 * WGRAD_SPLIT
+                    and dy2.is_contiguous() and x2.is_contiguous() and (weight.numel() % 4 == 0)):
+                slabs = _joint_wgrad(dy2, x2, raw=True)
+            if slabs is not None:
+                # the slices' partial products go straight into `.grad` (summed in order), autograd gets None
+                from caiman_asr_amd import _lib
+
+                if weight.grad is None:
+                    weight.grad = torch.zeros_like(weight)
+                _lib.check(_lib.lib().caiman_slab_accumulate(_lib.ptr(slabs), slabs.shape[0] if slabs.dim() == 3 else 1,
+                                                             weight.numel(), _lib.ptr(weight.grad), _lib.stream()))
+                notify_grad_ready(weight)
+            else:
+                dw = _weight_gradient(dy2, x2).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from caiman_asr_amd.rnnt_ext.transducer.loss import take_bias_gradient
 
@@ -252,6 +278,11 @@ def linear_transposed_backward(x, weight, bias):
     return _LinearTransposedBackward.apply(x, weight, bias)
 
 
+# Parameter gradients of the joint's input layers are accumulated by the GEMM that computes them (beta = 1 on the fp32
+# `.grad`, autograd gets None) instead of a product, a widening copy and AccumulateGrad's add.  CAIMAN_DIRECT_GRADS=0: returned.
+DIRECT_GRADS = __import__("os").environ.get("CAIMAN_DIRECT_GRADS", "1") != "0"
+
+
 class _LinearF32Grads(torch.autograd.Function):
     """torch.nn.Linear under autocast, except that the weight and bias gradients leave the GEMM / the column sum as fp32
     (autocast's own backward computes them in the 16-bit type and widens afterwards: one more rounding of every element of
@@ -262,32 +293,87 @@ class _LinearF32Grads(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        if bias is None:
-            return F.linear(x, weight, bias)
+        ctx.params = (weight, bias)
         # one GEMM with the bias in its epilogue, on the flattened CONTIGUOUS rows: handed a transposed view (the model passes
         # y.transpose(0, 1)), torch's linear falls back to matmul + a separate bias add -- a second rounding of every output
-        # element in the 16-bit type (29 % of the elements of g one to eleven ulps off, tools/bf16_forward_probe.py)
-        x2 = x.reshape(-1, x.shape[-1])
-        return torch.addmm(bias, x2, weight.t()).view(*x.shape[:-1], weight.shape[0])
+        # element in the 16-bit type (29 % of the elements of g one to eleven ulps off, tools/bf16_forward_probe.py).
+        # The 16-bit images of the rows and of the weight are made once, here, and kept for the backward pass.
+        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
+        x2 = x.reshape(-1, x.shape[-1]).to(dt)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = weight.to(dt)
+        ctx.save_for_backward(x2, w)
+        ctx.x_dtype = x.dtype
+        if bias is None:
+            return torch.mm(x2, w.t()).view(*x.shape[:-1], weight.shape[0])
+        return torch.addmm(bias.to(dt), x2, w.t()).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2, w = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy2 = dy.reshape(-1, dy.shape[-1]).to(x2.dtype)
         low = dy2.is_cuda and dy2.dtype in (torch.float16, torch.bfloat16)
+        direct = DIRECT_GRADS and low and weight.dtype == torch.float32
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, weight.to(dy2.dtype)).view(*dy.shape[:-1], weight.shape[1]).to(x.dtype)
+            dx = torch.mm(dy2, w).view(*dy.shape[:-1], w.shape[1]).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1]).to(dy2.dtype)
-            dw = (torch.mm(dy2.t(), x2, out_dtype=torch.float32) if low else torch.mm(dy2.t(), x2)).to(weight.dtype)
+            if direct:
+                if weight.grad is None:
+                    weight.grad = torch.zeros_like(weight)
+                torch.addmm(weight.grad, dy2.t(), x2, out_dtype=torch.float32, out=weight.grad)
+                notify_grad_ready(weight)
+            else:
+                dw = (torch.mm(dy2.t(), x2, out_dtype=torch.float32) if low else torch.mm(dy2.t(), x2)).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32 if low else dy2.dtype).to(weight.dtype)
+            # (the column sum as a product dy^T . 1 with a one-column operand takes the library 11 ms of HOST time per call on
+            # this stack, tools/torch_out_dtype_probe.py: the reduction stays a reduction)
+            db = dy2.sum(0, dtype=torch.float32 if low else dy2.dtype).to(bias.dtype)
         return dx, dw, db
 
 
 def linear_f32_grads(x, weight, bias):
     return _LinearF32Grads.apply(x, weight, bias)
+
+
+class _EmbeddingDirectGrad(torch.autograd.Function):
+    """torch.nn.functional.embedding whose weight gradient is added into `weight.grad` by one kernel with a fixed summation
+    order (include/caiman_rnnt.h caiman_embedding_grad) instead of the library's sort-based embedding_dense_backward (90 us
+    for the prediction network's 2 600 tokens) followed by AccumulateGrad's add."""
+
+    @staticmethod
+    def forward(ctx, idx, weight):
+        ctx.save_for_backward(idx)
+        ctx.weight = weight
+        return F.embedding(idx, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from caiman_asr_amd import _lib
+
+        (idx,) = ctx.saved_tensors
+        weight = ctx.weight
+        if weight.grad is None:
+            weight.grad = torch.zeros_like(weight)
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        tokens = idx.reshape(-1).long().contiguous()
+        _lib.check(_lib.lib().caiman_embedding_grad(_lib.ptr(tokens), tokens.numel(), _lib.ptr(dy2), _lib.dtype_tag(dy2.dtype),
+                                                    weight.shape[0], weight.shape[1], _lib.ptr(weight.grad), _lib.stream()))
+        notify_grad_ready(weight)
+        return None, None
+
+
+def embedding(module, idx):
+    """`module(idx)` for a torch.nn.Embedding; in training on the GPU with an fp32 table the gradient goes through
+    _EmbeddingDirectGrad (plain lookups only: no padding index, no max-norm, dense gradients)."""
+    w = module.weight
+    if (DIRECT_GRADS and w.is_cuda and w.dtype == torch.float32 and w.requires_grad and torch.is_grad_enabled() and w.is_contiguous()
+            and module.padding_idx is None and module.max_norm is None and not module.sparse and not module.scale_grad_by_freq):
+        return _EmbeddingDirectGrad.apply(idx, w)
+    return module(idx)

@@ -289,7 +289,7 @@ typedef struct {
   const void* src;
   float* dst;
   int32_t H, cols;
-  int32_t src_fp32, reserved;
+  int32_t src_fp32, slabs; /* slabs > 1 (fp32 sources only): src holds that many partial gradients, 4H * cols floats apart, summed in order */
 } caiman_lstm_grad_item_t;
 int caiman_lstm_grad_deliver(const caiman_lstm_grad_item_t* items, int n_items, int dtype, caiman_stream_t stream);
 
@@ -357,6 +357,10 @@ int caiman_wgrad_tn_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, 
 /* microseconds the plan's cost model expects (round quantisation over 256 CUs, per-workgroup fixed cost, slabs); < 0: shape
  * not supported.  For callers that keep the kernel to the calls where it is expected to beat their library product. */
 double caiman_wgrad_tn_estimate_us(int64_t M, int64_t N, int64_t K, int batch, int dtype);
+/* dst[i] += slabs[0][i] + ... + slabs[slices - 1][i] (n floats per slab, n % 4 == 0, 16-byte aligned): the slabs of a
+ * weight-gradient call summed in order into the parameter's fp32 gradient — autograd's AccumulateGrad and the reduction
+ * in front of it in one pass. */
+int caiman_slab_accumulate(const float* slabs, int slices, int64_t n, float* dst, caiman_stream_t stream);
 int caiman_wgrad_tn_covers_remainder(int64_t M, int64_t N, int64_t K, int slices, int64_t rows_per_slice);
 int caiman_wgrad_tn(const void* dY, int64_t stride_y, const void* H, int64_t stride_h, float* slabs, int batch, int64_t M,
                     int64_t N, int64_t K, int slices, int64_t rows_per_slice, int dtype, caiman_stream_t stream);
@@ -449,6 +453,14 @@ int caiman_logmel_forward(const float* audio, const int32_t* audio_len, int64_t 
 int caiman_mel_normalize(float* x, const int32_t* len, int64_t B, int nmel, int64_t T,
                          const float* ds_mean, const float* ds_std, float ratio,
                          caiman_stream_t stream);
+
+/* Gradient of an embedding table into its fp32 `.grad` — replaces autograd's embedding_dense_backward + AccumulateGrad for the
+ * prediction network's `torch.nn.Embedding` (training/caiman_asr_train/rnnt/model.py, `self.prediction["embed"]`):
+ * grad[v][:] += sum over n with tokens[n] == v of dy[n][:], positions in ascending order (fixed summation order).
+ * tokens [n] int64; dy [n][E] in `dtype` (CAIMAN_F32 / BF16 / F16), rows contiguous; grad [V][E] f32; tokens outside
+ * [0, V) contribute nothing. */
+int caiman_embedding_grad(const int64_t* tokens, int64_t n, const void* dy, int dtype, int64_t V, int64_t E, float* grad,
+                          caiman_stream_t stream);
 
 /* The (h, c) rows of every utterance's last valid step, all layers of a stack, in one launch — replaces the two
  * advanced-indexing selections of training/caiman_asr_train/train_utils/rsp.py:108-130 (`get_last_nonpadded_states`; with

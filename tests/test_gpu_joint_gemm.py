@@ -210,7 +210,7 @@ def test_projection_autograd_takes_the_handwritten_weight_gradient_and_agrees_wi
     dy = torch.randn(rows, N, device=DEV, generator=g).to(torch.bfloat16)
     calls, grads = [], []
     real = overlap._joint_wgrad
-    monkeypatch.setattr(overlap, "_joint_wgrad", lambda a, c: (calls.append(1), real(a, c))[1])
+    monkeypatch.setattr(overlap, "_joint_wgrad", lambda a, c, **kw: (calls.append(1), real(a, c, **kw))[1])
     assert overlap.JOINT_WGRAD, "the hand-written weight gradient is the default"
     for on in (True, False):
         monkeypatch.setattr(overlap, "JOINT_WGRAD", on)

@@ -455,3 +455,33 @@ def test_last_state_gather_kernel_equals_advanced_indexing(dtype, back):
         cols = torch.arange(B, device=DEV)
         assert torch.equal(got[0], h[:, idx, cols, :]) and torch.equal(got[1], c[:, idx, cols, :])
         assert got[0].is_contiguous() and got[0].shape == (L, B, H)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embedding_gradient_kernel_equals_autograd(dtype):
+    """caiman_embedding_grad (one launch, fixed summation order, accumulating into `.grad`) against torch's own embedding
+    backward: repeated tokens, tokens nobody emitted, more tokens than one staging block, an existing gradient to add to."""
+    from caiman_asr_amd.train_utils import overlap
+
+    V, E, B, U = 300, 192, 13, 170           # 2210 tokens: three staging blocks of 1024
+    g = torch.Generator().manual_seed(V + E)
+    emb = torch.nn.Embedding(V, E).to(DEV)
+    idx = torch.randint(0, V // 2, (B, U), generator=g).to(DEV)      # the upper half of the table is never looked up
+    w = torch.randn(B, U, E, generator=g).to(DEV).to(dtype)
+    for trial in range(2):                    # the second pass accumulates on top of the first
+        out = overlap.embedding(emb, idx)
+        assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_EmbeddingDirectGrad")
+        (out.to(dtype) * w).float().sum().backward()
+    got = emb.weight.grad.clone()
+    ref_mod = torch.nn.Embedding(V, E).to(DEV)
+    ref_mod.load_state_dict(emb.state_dict())
+    for trial in range(2):
+        (ref_mod(idx).to(dtype) * w).float().sum().backward()
+    ref = ref_mod.weight.grad
+    assert torch.equal(got[V // 2:], torch.zeros_like(got[V // 2:]))
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+    # bit-identical from run to run
+    emb.weight.grad = None
+    for trial in range(2):
+        (overlap.embedding(emb, idx).to(dtype) * w).float().sum().backward()
+    assert torch.equal(emb.weight.grad, got)
