@@ -212,14 +212,20 @@ class EncoderPipeFunction(torch.autograd.Function):
         Gb = torch.empty((Lb, T2, B, 4 * H), dtype=dt, device=dev)
         torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=Ga[0].view(T1 * B, 4 * H))
         # pre outputs carry f-1 zero frames at the end so that the last stacked frame is zero padded (StackTime)
-        Ya = torch.zeros((La, T1p + 1, B, H), dtype=dt, device=dev) if T1p != T1 else torch.empty((La, T1 + 1, B, H), dtype=dt, device=dev)
+        # (only the padding frames are cleared: the kernels write every other row)
+        Ya = torch.empty((La, T1p + 1, B, H), dtype=dt, device=dev)
+        if T1p != T1:
+            Ya[:, T1 + 1:].zero_()
         Ca = torch.empty((La, T1 + 1, B, H), dtype=dt, device=dev)
         Yb = torch.empty((Lb, T2 + 1, B, H), dtype=dt, device=dev)
         Cb = torch.empty((Lb, T2 + 1, B, H), dtype=dt, device=dev)
-        Ya[:, 0].copy_(h0a)
-        Ca[:, 0].copy_(c0a)
-        Yb[:, 0].copy_(h0b)
-        Cb[:, 0].copy_(c0b)
+        def first_row(buf, state):   # initial state into row 0; None (no carried state): zeros without a tensor of zeros
+            buf[:, 0].zero_() if state is None else buf[:, 0].copy_(state)
+
+        first_row(Ya, h0a)
+        first_row(Ca, c0a)
+        first_row(Yb, h0b)
+        first_row(Cb, c0b)
         G = [Ga[l] for l in range(La)] + [Gb[m] for m in range(Lb)]
         Y = [Ya[l] for l in range(La)] + [Yb[m] for m in range(Lb)]
         C = [Ca[l] for l in range(La)] + [Cb[m] for m in range(Lb)]
@@ -228,8 +234,8 @@ class EncoderPipeFunction(torch.autograd.Function):
             Gp = torch.empty((Lp, Tp, B, 4 * Hp), dtype=dt, device=dev)
             Yp = torch.empty((Lp, Tp + 1, B, Hp), dtype=dt, device=dev)
             Cp = torch.empty((Lp, Tp + 1, B, Hp), dtype=dt, device=dev)
-            Yp[:, 0].copy_(h0p)
-            Cp[:, 0].copy_(c0p)
+            first_row(Yp, h0p)
+            first_row(Cp, c0p)
             torch.addmm(bias[Le], xp.flatten(0, 1).to(dt), Wp[Le], out=Gp[0].view(Tp * B, 4 * Hp))
             G += [Gp[p] for p in range(Lp)]
             Y += [Yp[p] for p in range(Lp)]
@@ -239,8 +245,9 @@ class EncoderPipeFunction(torch.autograd.Function):
         pl = [drop_e] * Le + [drop_p] * Lp                    # dropout applied to the OUTPUT of layer l when it feeds a layer
         top = {Le - 1} | ({L - 1} if Lp else set())            # top layers: their output dropout is the caller's
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (drop_e > 0.0 or drop_p > 0.0) else 0
-        YMa = (torch.zeros((La, T1p, B, H), dtype=dt, device=dev) if T1p != T1 else torch.empty((La, T1, B, H), dtype=dt, device=dev)) \
-            if drop_e > 0.0 else None
+        YMa = torch.empty((La, T1p, B, H), dtype=dt, device=dev) if drop_e > 0.0 else None
+        if YMa is not None and T1p != T1:
+            YMa[:, T1:].zero_()
         YMb = torch.empty((max(Lb - 1, 1), T2, B, H), dtype=dt, device=dev) if drop_e > 0.0 else None
         YMp = torch.empty((Lp - 1, Tp, B, Hp), dtype=dt, device=dev) if drop_p > 0.0 else None
         YM = [None] * L
@@ -656,8 +663,7 @@ class EncoderPipeFunction(torch.autograd.Function):
 
 def _states(state, L, B, H, like):
     if state is None:
-        z = torch.zeros((L, B, H), device=like.device, dtype=like.dtype)
-        return z, torch.zeros_like(z)
+        return None, None          # the function clears the first row of its own buffers
     return state[0].detach(), state[1].detach()
 
 

@@ -161,8 +161,7 @@ class CustomLSTM(torch.nn.Module):
             # whole-stack layer pipeline (same kernels and GEMM operands, different schedule)
             L = self.num_layers
             if state is None:
-                h0 = torch.zeros((L, input.shape[1], self.hidden_size), device=input.device, dtype=input.dtype)
-                c0 = torch.zeros_like(h0)
+                h0 = c0 = None           # the function clears the first row of its own buffers
             else:
                 h0, c0 = state[0].detach(), state[1].detach()
             params = []

@@ -138,8 +138,9 @@ class StackFunction(torch.autograd.Function):
         torch.addmm(bias[0], x.flatten(0, 1).to(dt), Wp[0], out=G[0].view(T * B, 4 * H))
         Y = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
         Cs = torch.empty((L, T + 1, B, H), dtype=dt, device=dev)
-        Y[:, 0].copy_(h0)
-        Cs[:, 0].copy_(c0)
+        # initial state into row 0; None (no carried state): zeros without a tensor of zeros
+        Y[:, 0].zero_() if h0 is None else Y[:, 0].copy_(h0)
+        Cs[:, 0].zero_() if c0 is None else Cs[:, 0].copy_(c0)
         drop = float(p_drop) if (training and p_drop > 0.0 and L > 1) else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop > 0.0 else 0
         YM = torch.empty((L - 1, T, B, H), dtype=dt, device=dev) if drop > 0.0 else None  # masked outputs
