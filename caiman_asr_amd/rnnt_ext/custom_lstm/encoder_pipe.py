@@ -270,7 +270,10 @@ class EncoderPipeFunction(torch.autograd.Function):
             ring.append(ring_all[off:off + 2 * bp * h])
             off += 2 * bp * h
         st = _lib.stream()
+        zero_state = [h0a is None] * La + [h0b is None] * Lb + [h0p is None] * Lp
         for l in range(L):
+            if fused_img and zero_state[l]:
+                continue     # nothing to prepare: the weight images exist and a zero initial state is what the cleared ring holds
             _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), _lib.ptr(Y[l][0]), _lib.ptr(wt[l]),
                                                 _lib.ptr(ring[l]), None, B, Hl[l], tag, 0, INTERLEAVED | RINGS_ZEROED, st))
         CH = _chunk(H)
@@ -430,7 +433,9 @@ class EncoderPipeFunction(torch.autograd.Function):
             dC.append(zero_all[off:off + dc_b[l]].view(torch.float32))
             off += (dc_b[l] + 15) // 16 * 16
         for l in range(L):
-            _lib.check(lib.caiman_lstm_prepare(None if flags[3] else _lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
+            if flags[3]:
+                continue     # images saved by the forward pass, rings and carries cleared above: nothing left to prepare
+            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
                                                 _lib.ptr(dC[l]), B, Hl[l], tag, 1, INTERLEAVED | RINGS_ZEROED, st))
         CH = _chunk(H)
         CHb = _post_chunk(f, CH)

@@ -145,10 +145,13 @@ class StackFunction(torch.autograd.Function):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop > 0.0 else 0
         YM = torch.empty((L - 1, T, B, H), dtype=dt, device=dev) if drop > 0.0 else None  # masked outputs
         ring = _Scratch.get("fr", L * 2 * bp * H, dt, dev).view(L, -1)
+        ring.zero_()     # the h rings of all layers in one memset
         st = _lib.stream()
         for l in range(L):
+            if fused_img and h0 is None:
+                continue     # nothing to prepare: the weight images exist and a zero initial state is what the cleared ring holds
             _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), _lib.ptr(Y[l, 0]), _lib.ptr(wt[l]),
-                                                _lib.ptr(ring[l]), None, B, H, tag, 0, INTERLEAVED, st))
+                                                _lib.ptr(ring[l]), None, B, H, tag, 0, INTERLEAVED | RINGS_ZEROED, st))
         CH = _chunk(L, T)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), False)
@@ -222,15 +225,22 @@ class StackFunction(torch.autograd.Function):
             d_top = d_top + extra[L - 1]
         bp = _pad32(B)
         wt = list(Rp) if fused_img else _Scratch.get("bw", L * 4 * H * H, dt, dev).view(L, -1)   # fused: the saved images
-        ring = _Scratch.get("br", L * 2 * bp * 4 * H, dt, dev).view(L, -1)
-        dC = _Scratch.get("bc", L * B * H, torch.float32, dev).view(L, -1)
+        # dG rings (16-bit) and dC carries (fp32) of all layers in one byte buffer: one memset instead of two per layer
+        ring_b, dc_b = L * 2 * bp * 4 * H * G.element_size(), L * B * H * 4
+        ring_pad = (ring_b + 15) // 16 * 16
+        zero_all = _Scratch.get("bz_all", ring_pad + dc_b, torch.uint8, dev)
+        zero_all.zero_()
+        ring = zero_all[:ring_b].view(dt).view(L, -1)
+        dC = zero_all[ring_pad:ring_pad + dc_b].view(torch.float32).view(L, -1)
         # bias gradients from the backward kernels (BwdSlot.dbias) where the weight-resident kernels run; otherwise one
         # reduction per layer at the end (cheaper than the per-timestep path's extra launch per call)
         fused_db = bool(lib.caiman_lstm_resident_would_run(B, H, min(8, L)))
         dbias = torch.zeros((L, 4 * H), dtype=torch.float32, device=dev) if fused_db else None
         for l in range(L):
-            _lib.check(lib.caiman_lstm_prepare(None if fused_img else _lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
-                                                _lib.ptr(dC[l]), B, H, tag, 1, INTERLEAVED, st))
+            if fused_img:
+                continue     # images saved by the forward pass, rings and carries cleared above: nothing left to prepare
+            _lib.check(lib.caiman_lstm_prepare(_lib.ptr(Rp[l]), None, _lib.ptr(wt[l]), _lib.ptr(ring[l]),
+                                                _lib.ptr(dC[l]), B, H, tag, 1, INTERLEAVED | RINGS_ZEROED, st))
         CH = _chunk(L, T)
         n_ch = (T + CH - 1) // CH
         sb = _step_bytes(B, H, G.element_size(), True)
