@@ -473,11 +473,13 @@ int wgrad_plan(int64_t M, int64_t N, int64_t K, int batch, int dtype, int64_t* r
   }();
   // (round 4: slices are multiples of 128 rows -- pairs of the 8-phase kernel's 64-row tiles; 1.40 us per tile and 35 us per
   // round of workgroups fitted to tools/wgrad_tn_bench.py: 153 / 443 / 597 / 1391 us measured for 1 x 17 792, 5 and 6 x 8 896, 6 x 35 584 rows)
-  // (the rows the slices do not cover -- fewer than 128 per slice -- ride in the last slice: its workgroups decide the round)
+  // (the rows the slices do not cover -- fewer than 128 per slice -- ride in the last slice since the descriptor-bounded
+  // kernel; the `rest` term, fitted when they were a library product of the caller's, still ranks the slice counts the way
+  // the measurements do: 16 slices beat 15 / 11 at 0.8 - 1.25 M rows x 17408 x 1024 by 1 - 2 %, tools/joint_wgrad_rows.py)
   auto cost = [&](int64_t c) {
-    const int64_t rounds = (tiles * c + kCus - 1) / kCus, per_c = M / (128 * c) * 128;
-    const int64_t steps = (M - (c - 1) * per_c + 127) / 128 * 2;
-    return (double)rounds * ((double)steps * 1.40e-6 + 35e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12;
+    const int64_t rounds = (tiles * c + kCus - 1) / kCus, steps = M / (128 * c) * 2, rest = M - c * steps * 64;
+    return (double)rounds * ((double)steps * 1.40e-6 + 35e-6) + (double)(c * batch) * (double)(N * K) * 8.0 / 5e12 +
+           (rest > 0 ? 15e-6 + (double)(rest * batch) * (double)(N * K) * 2.0 / 0.9e15 : 0.0);
   };
   int64_t s = 1;
   double best = 1e30;

@@ -386,7 +386,7 @@ def test_weight_gradient_plan_and_cost_model_are_host_logic():
     assert plan(304000, 8704, 768) == (5, 60800)            # joint projection: 102 tiles x 5 = 510 workgroups, two rounds
     assert lib.caiman_joint_fc_wgrad_plan(304000, 8704, 768, bf16, ctypes.byref(per)) == 5 and per.value == 60800
     s, rows = plan(304000, 17408, 1024)                      # large-196M: 272 tiles, one slice would be 1.06 rounds
-    assert s >= 5 and s * rows <= 304000 and rows % 128 == 0 and 304000 - s * rows < 128 * s   # slices: pairs of 64-row tiles
+    assert s >= 8 and s * rows <= 304000 and rows % 128 == 0 and 304000 - s * rows < 128 * s   # slices: pairs of 64-row tiles
     assert plan(8896, 4096, 1024, 6) == (2, 4352)            # six LSTM layers: 384 tiles x 2 = 3 rounds, the last 192 rows ride in the last slice
     for M, N, K, P in [(200, 512, 512, 1), (4096, 500, 512, 1), (4096, 512, 240, 1), (4096, 512, 512, 0)]:
         assert plan(M, N, K, P)[0] == 0

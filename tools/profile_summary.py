@@ -22,7 +22,10 @@ NAMES = ("lstm_bwd_resident2_bt_dma|lstm_bwd_resident2_bt|lstm_fwd_resident_bt_d
          "lstm_bwd_step_mfma|lstm_fwd_step_mfma|loss_bwd_colsum_kernel|loss_row_desc_kernel|loss_bwd_kernel|loss_fwd_kernel|lse_rows_kernel|"
          "lse_partials_kernel|joint_fc_gemm8_kernel|joint_fc_gemm_kernel|joint_wgrad8_kernel|joint_wgrad_kernel|occupy_cus_kernel|joint_bwd_kernel|joint_fwd_kernel|lamb_stage1|lamb_stage2|gnorm_kernel|beam_topk_reg_kernel|beam_topk_kernel|"
          "lstm_cell_kernel|gather_inputs_kernel|joint_act_kernel|proj_gemm_kernel|lstm_images_kernel|lstm_grad_deliver_kernel|logmel_kernel|"
-         "mel_normalize_kernel|specaug_splice_kernel|dbias_rows_kernel")
+         "mel_normalize_kernel|specaug_splice_kernel|dbias_rows_kernel|"
+         # round 4, launch sweep: this repo's small kernels by name (until then they sat in "other" with the torch glue)
+         "embedding_grad_kernel|slab_accumulate_kernel|lstm_last_states_kernel|specaug_geometry_kernel|gnorm_partial_kernel|"
+         "gnorm_final_kernel|lamb_ratio_kernel|tile_rows_kernel|dropout_mask_kernel")
 
 
 def short(name):
