@@ -22,6 +22,23 @@ from caiman_asr_amd import _lib
 from caiman_asr_amd.rnnt import streaming_lstm
 
 _SPIN_WAIT = __import__("os").environ.get("CAIMAN_BEAM_SPIN", "0") != "0"   # polling the event instead of stream-synchronise: no gain measured (p50 10.9-11.6 ms either way)
+# One expansion round = index upload + gather + two cell GEMMs + joint_pred + relu-add + joint_fc + top-k + result download.
+# The host waits for every round's result, so the ~10 us each of those nine commands takes to issue sits on the tick's
+# critical path 20-30 times per tick.  CAIMAN_BEAM_GRAPH=1: the round is captured once per bucket of row counts as a
+# hipGraph and replayed with one launch; rows are padded up to the bucket (the padding rows read the zero state and encoder
+# row 0 and write into a spare pool row).  Default since round 4 (2 000 streams: p50 of the tick 8.1-8.9 -> 6.9-7.2 ms, same
+# tokens); 0: nine eager launches per round.
+ROUND_GRAPH = __import__("os").environ.get("CAIMAN_BEAM_GRAPH", "1") != "0"
+
+
+def _rows_bucket(n: int) -> int:
+    """rows of a captured round: 64, 128, 256, 512, then multiples of 256 (at most 25 % of padding above 1024 rows)"""
+    b = 64
+    while b < n and b < 512:
+        b *= 2
+    return b if n <= b else (n + 255) // 256 * 256
+
+
 from caiman_asr_amd.rnnt.decoder import RNNTCommonDecoder, StreamingEncoder
 from caiman_asr_amd.rnnt.eos_strategy import EOSBlank, EOSIgnore, EOSPredict
 from caiman_asr_amd.rnnt.response import DecodingResponse, FrameResponses, HypothesisResponse
@@ -213,6 +230,7 @@ class HipBeamStep:
         self.h_pool = self.c_pool = None
         self.cap = 0
         self.stats = None
+        self.graphs = {}     # (rows bucket, operand addresses) -> captured round (hipGraph): one launch instead of nine
 
     def _weights(self, cd):
         w = self.w.get(cd)
@@ -238,8 +256,9 @@ class HipBeamStep:
 
     def _ensure(self, n_slots: int, n: int, dev, cd):
         L, H, k = self.L, self.H, self.k
-        if self.h_pool is None or self.h_pool.shape[1] < n_slots + 1 or self.h_pool.dtype != cd:
-            rows = max(2 * n_slots, 64) + 1
+        if self.h_pool is None or self.h_pool.shape[1] < n_slots + 2 or self.h_pool.dtype != cd:
+            rows = max(2 * n_slots, 64) + 2       # row 0: the zero start state; last row: where a captured round's padding rows write
+            self.graphs.clear()                   # captured rounds hold the old pools' addresses
             h = torch.zeros(L, rows, H, device=dev, dtype=cd)
             c = torch.zeros(L, rows, H, device=dev, dtype=torch.float32)
             if self.h_pool is not None:
@@ -248,6 +267,7 @@ class HipBeamStep:
             self.h_pool, self.c_pool = h, c
         if self.cap < n or self.X[0].dtype != cd:
             cap = self.cap = max(2 * n, 256)
+            self.graphs.clear()
             m = self.model
             E, Hj, V = m.prediction["embed"].weight.shape[1], m.joint_pred.weight.shape[0], m.joint_fc.weight.shape[0]
             self.idx_host = torch.empty(6, cap, dtype=torch.int32).pin_memory()    # y, in, out, row (int64 = 2 rows), pad
@@ -277,6 +297,49 @@ class HipBeamStep:
         ih = self.idx_host.numpy()
         ih[0, :n], ih[1, :n], ih[2, :n] = y_last, state_in, state_out
         ih[3:5].reshape(-1).view(np.int64)[:n] = rows
+        nb = n
+        if ROUND_GRAPH:
+            # the round as ONE graph launch, captured per bucket of row counts; the padding rows start from the zero state,
+            # read encoder row 0 and write their state into the pools' spare last row
+            nb = _rows_bucket(n)
+            self._ensure(n_slots, nb, dev, cd)
+            ih = self.idx_host.numpy()
+            if nb > n:
+                ih[0, n:nb], ih[1, n:nb], ih[2, n:nb] = 0, -1, self.h_pool.shape[1] - 2
+                ih[3:5].reshape(-1).view(np.int64)[n:nb] = 0
+            key = (nb, frames2d.data_ptr(), tuple(frames2d.shape), cd, id(w))
+            g = self.graphs.get(key)
+            if g is None:
+                # once eagerly, so that the library's handles and workspaces exist before the capture (the round reads its
+                # states from slots it does not write, so running it twice leaves the same result)
+                self._round(frames2d, nb, w, cd)
+                torch.cuda.current_stream().synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (a data feed) may use the GPU meanwhile
+                    self._round(frames2d, nb, w, cd)
+                self.graphs[key] = g
+            g.replay()
+        else:
+            self._round(frames2d, n, w, cd)
+        k = self.k
+        if _SPIN_WAIT:   # a round is ~0.2 ms of device work on the tick's critical path, 26 times per tick: poll the event
+            ev = self._done if self._done is not None else torch.cuda.Event()   # instead of sleeping in stream synchronise
+            self._done = ev
+            ev.record()
+            while not ev.query():
+                pass
+        else:
+            torch.cuda.current_stream().synchronize()
+        hn = self.out_host.numpy()      # laid out for nb rows (nb = n without the graph): scores | tokens | blank
+        if self.stats is not None:   # [sum of top-1 probabilities, rows]: how peaked the workload is
+            self.stats[0] += float(np.exp(hn[: n * k: k]).sum())
+            self.stats[1] += n
+        return (hn[: nb * k].reshape(nb, k)[:n], hn[nb * k: 2 * nb * k].view(np.int32).reshape(nb, k)[:n],
+                hn[2 * nb * k: 2 * nb * k + nb][:n])
+
+    def _round(self, frames2d, n, w, cd):
+        """the device work of one expansion round for n rows of the index buffers, on the current stream (eager or captured)"""
+        dev, k, L, H = frames2d.device, self.k, self.L, self.H
         self.idx_dev.copy_(self.idx_host, non_blocking=True)
         y, s_in, s_out = (_lib.ptr(self.idx_dev[i]) for i in range(3))
         row = _lib.ptr(self.idx_dev[3])
@@ -305,19 +368,6 @@ class HipBeamStep:
                                         self.eos[0], self.eos[1], self.eos[2], self.eos[3], k, _lib.ptr(sc),
                                         _lib.ptr(tk), _lib.ptr(bl), st))
         self.out_host[: 2 * n * k + n].copy_(flat[: 2 * n * k + n], non_blocking=True)
-        if _SPIN_WAIT:   # a round is ~0.2 ms of device work on the tick's critical path, 26 times per tick: poll the event
-            ev = self._done if self._done is not None else torch.cuda.Event()   # instead of sleeping in stream synchronise
-            self._done = ev
-            ev.record()
-            while not ev.query():
-                pass
-        else:
-            torch.cuda.current_stream().synchronize()
-        hn = self.out_host.numpy()
-        if self.stats is not None:   # [sum of top-1 probabilities, rows]: how peaked the workload is
-            self.stats[0] += float(np.exp(hn[: n * k: k]).sum())
-            self.stats[1] += n
-        return (hn[: n * k].reshape(n, k), hn[n * k: 2 * n * k].view(np.int32).reshape(n, k), hn[2 * n * k: 2 * n * k + n])
 
 
 class RNNTBeamDecoderNative(RNNTCommonDecoder):

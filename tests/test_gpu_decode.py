@@ -222,6 +222,42 @@ def test_streaming_beam_equals_offline():
     assert [sorted(r) for r in merged] == [sorted(r) for r in off]
 
 
+def test_captured_round_equals_eager_round(monkeypatch):
+    """The expansion round as ONE captured graph launch per bucket of row counts (rows padded up to the bucket: the padding
+    starts from the zero state and writes into a spare pool row) against the nine eager launches: same tokens, timestamps and
+    response keys, scores to GEMM rounding (the products run at the bucket's row count); row counts on both sides of a bucket
+    edge, a pool that grows between ticks (the captured rounds are dropped and captured again)."""
+    from caiman_asr_amd.rnnt import beam_native
+    from caiman_asr_amd.rnnt.decoder import flatten_responses
+    from tests.test_beam_host import BEAM, PIECES
+
+    g, m = build("mfma")
+    with torch.no_grad():
+        m.joint_fc.bias[0] = BEAM["unk_bias"]
+    V = int(g["n_classes"])
+    torch.manual_seed(11)
+    T, B = 24, 70                  # first rounds serve 70 requests (bucket 128), later ones fewer than 64
+    x = torch.randn(T, B, g["x"].shape[2], device=DEV)
+    results, captured = [], 0
+    for graph in (False, True):
+        monkeypatch.setattr(beam_native, "ROUND_GRAPH", graph)
+        dec = beam_native.StreamingBeamDecoder(m, V - 1, B, PIECES)
+        merged = [dict() for _ in range(B)]
+        for t0 in range(0, T, 2):
+            for b, r in enumerate(dec.step(x[t0:t0 + 2])):
+                merged[b].update(r)
+        for b, r in enumerate(dec.close()):
+            merged[b].update(r)
+        captured += len(dec.dec.step.graphs)
+        results.append((flatten_responses(merged), [sorted(r) for r in merged]))
+    assert captured >= 2, "fewer than two buckets were captured: the test does not cross a bucket edge"
+    (tk0, ts0, cf0), keys0 = results[0]
+    (tk1, ts1, cf1), keys1 = results[1]
+    assert tk0 == tk1 and ts0 == ts1 and keys0 == keys1 and sum(map(len, tk0)) > 50
+    for a, b in zip(cf0, cf1):
+        assert np.allclose(a, b, atol=1e-4)
+
+
 def test_streaming_beam_stragglers_catch_up():
     """Ending ticks early (slow streams keep their frame and queue the new ones) changes when responses appear,
     not what they are."""
