@@ -307,17 +307,24 @@ class HipBeamStep:
             if nb > n:
                 ih[0, n:nb], ih[1, n:nb], ih[2, n:nb] = 0, -1, self.h_pool.shape[1] - 2
                 ih[3:5].reshape(-1).view(np.int64)[n:nb] = 0
-            key = (nb, frames2d.data_ptr(), tuple(frames2d.shape), cd, id(w))
-            g = self.graphs.get(key)
+            env = (frames2d.data_ptr(), tuple(frames2d.shape), cd, id(w))
+            g = self.graphs.get((nb,) + env)
             if g is None:
-                # once eagerly, so that the library's handles and workspaces exist before the capture (the round reads its
-                # states from slots it does not write, so running it twice leaves the same result)
+                # Capture EVERY bucket the buffers can hold now (a tick that meets a new row count later must not pay
+                # for a capture: 5-10 ms each).  Before the first one the round runs once eagerly, so that the library's
+                # handles and workspaces exist (it reads its states from slots it does not write: running it twice leaves
+                # the same result).
                 self._round(frames2d, nb, w, cd)
                 torch.cuda.current_stream().synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (a data feed) may use the GPU meanwhile
-                    self._round(frames2d, nb, w, cd)
-                self.graphs[key] = g
+                b = 64
+                while b <= self.cap:
+                    if (b,) + env not in self.graphs:
+                        gb = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gb, capture_error_mode="thread_local"):   # other threads (a data feed) may use the GPU meanwhile
+                            self._round(frames2d, b, w, cd)
+                        self.graphs[(b,) + env] = gb
+                    b = b * 2 if b < 512 else b + 256
+                g = self.graphs[(nb,) + env]
             g.replay()
         else:
             self._round(frames2d, n, w, cd)
