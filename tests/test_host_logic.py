@@ -400,3 +400,36 @@ def test_weight_gradient_plan_and_cost_model_are_host_logic():
     # five layers fill 2.5 rounds: the model prices them above the library's 0.8 PF/s, and the caller keeps the library
     flops = 2.0 * 5 * 8896 * 4096 * 1024
     assert est(8896, 4096, 1024, 5, bf16) * 1e-6 > flops / 0.8e15
+
+
+def test_round_buckets_and_mask_geometry_arithmetic_are_host_logic():
+    """Host-side pieces of the round-4 launch sweep: the row-count buckets of the captured beam round (every count maps to a
+    bucket that holds it, at most 25 % of padding above 1 024 rows, and the bucket list the capture loop walks contains
+    it) and SpecAugment's arithmetic on given draws (widths and starts inside the reference's ranges, adaptive counts)."""
+    import torch
+
+    from caiman_asr_amd.data.features import SpecAugment
+    from caiman_asr_amd.rnnt.beam_native import _rows_bucket
+
+    walked, b = [], 64
+    while b <= 8192:
+        walked.append(b)
+        b = b * 2 if b < 512 else b + 256
+    for n in list(range(1, 700)) + [1023, 1024, 1025, 2000, 4095, 4097, 8000]:
+        nb = _rows_bucket(n)
+        assert nb >= n and nb in walked, (n, nb)
+        assert nb == 64 or nb < 2 * n
+        if n > 1024:
+            assert nb - n < 256 and nb <= 1.25 * n
+    sa = SpecAugment(freq_masks=2, min_freq=0, max_freq=20, time_masks=0.04, min_time=0, max_time=0.03)
+    B, F, T = 5, 80, 1000
+    lens = torch.tensor([1000.0, 500.0, 250.0, 100.0, 12.0])
+    r = torch.rand(B, 2 * sa.freq_masks + 2 * sa._time_slots(T), generator=torch.Generator().manual_seed(3))
+    f0, fw, t0, tw = sa.geometry_from_draws(r, lens, F, T)
+    assert f0.shape == fw.shape == (B, 2) and t0.shape == tw.shape == (B, 41)
+    assert bool(((fw >= 0) & (fw <= 20) & (f0 >= 0) & (f0 + fw <= F)).all())
+    assert bool(((tw >= 0) & (t0 >= 0) & (t0 + tw <= T)).all())
+    for b_ in range(B):
+        n_masks, max_w = round(float(lens[b_]) * 0.04), round(float(lens[b_]) * 0.03)
+        assert bool((tw[b_, n_masks:] == 0).all()) and bool((tw[b_] <= max_w).all())
+    assert bool((r.min() >= 0) and (r.max() < 1))
