@@ -348,6 +348,9 @@ def main():
                     help="after the timed loop, run N more steps under torch.profiler (with Python stacks) and write, per kernel "
                          "name and calling source line of this repo, launches and device time per step to stderr: where the "
                          "step's small torch kernels come from")
+    ap.add_argument("--no-prewarm", action="store_true",
+                    help="skip the allocator pre-warm passes over the largest batches (profile runs: with --steps 6 --warmup 0 the "
+                         "process then executes exactly one pass over the six synthetic batches, the mix of the timed loop)")
     ap.add_argument("--feed", action="store_true",
                     help="after the timed loop, time the same steps again WHILE the data feed (AudioBatchLoader: 8 FLAC decode "
                          "threads, side-stream log-mel / normalise / splice kernels) produces one batch per step (N = 1 only)")
@@ -499,7 +502,7 @@ def main():
 
     by_cells = max(range(n_distinct), key=lattice_cells)                       # largest logits / gradient tensors
     by_frames = max(range(n_distinct), key=lambda j: host_batches[j][0].numel())  # largest LSTM activations
-    for j in dict.fromkeys((by_cells, by_frames)):
+    for j in ([] if args.no_prewarm else dict.fromkeys((by_cells, by_frames))):
         step(j, 0)
         step(j, 0)   # twice, back to back: the timed loop keeps two steps in flight, so it needs two steps' worth of blocks
     optimizer._step.zero_()
@@ -715,7 +718,41 @@ def main():
                     "per_product": {k[11:]: {"ms_per_step": v[1] / args.steps, "tflops": v[3] / (v[1] * 1e-3) / 1e12}
                                     for k, v in jg.items()},
                     "note": "live HIP events around each call; rocprofv3 counterparts in profiles/r04_base_summary.md "
-                            "(64.5 % / 69.3 % SQ_VALU_MFMA_BUSY)"}
+                            "(64.3 % / 69.4 % SQ_VALU_MFMA_BUSY)"}
+            # The `roofline` record is the DOMINANT kernel's.  Since the hand-written projection GEMM became the default that
+            # is joint_fc_gemm8_kernel (two launches per step: forward + row LSE, input gradient; 22.8 % of the step's kernel
+            # time in profiles/r04_base_summary.md against 17.2 % for the backward recurrence), MFMA-bound; the recurrence's
+            # record, the dominant one of rounds 1-3, stays beside it as `roofline_lstm_bwd`.
+            jk = {k: summ[k] for k in ("joint_gemm_fwd", "joint_gemm_dx") if k in summ}
+            if len(jk) == 2:
+                if "roofline" in out:
+                    out["roofline_lstm_bwd"] = out.pop("roofline")
+                flop, ms = sum(v[3] for v in jk.values()), sum(v[1] for v in jk.values())
+                n_l = sum(v[0] for v in jk.values())
+                tfl = flop / (ms * 1e-3) / 1e12
+                rec = {"kernel": "joint_fc_gemm8_kernel (C = A . W^T + bias on 256 x 256 tiles, 8-phase MFMA main loop, persistent "
+                                 "workgroups; per step one launch with the row log-sum-exp epilogue and one for the input gradient)",
+                       "bound": "mfma", "achieved": tfl, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_PEAK_TFLOPS,
+                       "traffic": None, "avg_launch_us": ms * 1e3 / n_l, "launches": n_l,
+                       "algorithmic_flop_per_launch": flop / n_l,
+                       "note": ("live HIP events around each call (the forward bracket also holds the 0.17 ms reduction of the LSE "
+                                "partials); achieved = 2 M N K of the timed launches / their time; peak = dense bf16 MFMA at the "
+                                "guide's 2.5 PFLOP/s")}
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["joint_fc_gemm8_kernel"]
+                    rec["traffic"] = pmc["traffic_bytes_per_launch"]
+                    rec["from_profiles"] = {"source": f"profiles/{PMC_FILE} (builder-run rocprofv3 --pmc / --kernel-trace passes, NOT "
+                                                      "measured in this run; its launches are those of the profile command's "
+                                                      "steps, whose batches differ from the timed loop's mix: compare rates, not "
+                                                      "durations)",
+                                            "traffic_bytes_per_launch": pmc["traffic_bytes_per_launch"],
+                                            "rocprof_kernel_avg_us": pmc.get("kernel_avg_us"),
+                                            "mfma_busy_frac": pmc.get("mfma_util"),
+                                            "hbm_side_rate_gbs": pmc.get("hbm_side_rate_gbs"),
+                                            "same_launch_population": pmc.get("same_population")}
+                except Exception:
+                    pass
+                out["roofline"] = rec
             if "loss_bwd" in summ:
                 n_launch, ms = summ["loss_bwd"][0], summ["loss_bwd"][1]
                 alg = cells * N_CLASSES * 2 * 2  # V*s read + V*s write per lattice cell

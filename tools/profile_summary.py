@@ -42,21 +42,46 @@ def short(name):
     return None
 
 
-def counter_pass(root, counter):
+STEP_END = "lamb_stage2"     # the last kernel of a training step: `last=N` keeps the dispatches of the final N steps
+
+
+def _last_steps(names, last):
+    """index range [lo, hi) of the dispatches (in launch order) that make up the final `last` steps, or None"""
+    ends = [i for i, n in enumerate(names) if STEP_END in n]
+    if last is None or len(ends) < last + 1:
+        return None
+    return ends[-last - 1] + 1, ends[-1] + 1
+
+
+def counter_pass(root, counter, last=None):
     acc = defaultdict(lambda: [0.0, 0])
     for f in glob.glob(f"{root}/{counter}/**/*counter_collection.csv", recursive=True):
+        per = {}       # dispatch id -> [kernel name, summed value]: a counter may come as several rows per dispatch
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                k = short(row["Kernel_Name"])
-                if k is None or row["Counter_Name"] != counter:
+                if row["Counter_Name"] != counter:
                     continue
-                acc[k][0] += float(row["Counter_Value"])
-                acc[k][1] += 1
+                e = per.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])
+                e[1] += float(row["Counter_Value"])
+        ids = sorted(per)
+        rng = _last_steps([per[i][0] for i in ids], last)
+        if rng:
+            ids = ids[rng[0]:rng[1]]
+        for i in ids:
+            k = short(per[i][0])
+            if k is None:
+                continue
+            acc[k][0] += per[i][1]
+            acc[k][1] += 1
     return {k: {"avg": v[0] / v[1], "dispatches": v[1]} for k, v in acc.items()}
 
 
-def main(root, tag, steps, title=None):
+def main(root, tag, steps, title=None, last=None):
+    """last = N (sixth argument `last=N`): only the final N training steps of the traced process count (delimited by the
+    optimiser's last kernel) -- the timed steps of a bench run, without its allocator pre-warm and warm-up steps, so that
+    per-launch averages of size-dependent kernels are those of the bench's own batch mix."""
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    last = int(str(last).split("=")[-1]) if last else None
     if steps == "auto":   # the program's own JSON line in the kernel-trace pass's log says how many steps / ticks it ran
         steps = None
         for ln in open(f"{root}/stats.log"):
@@ -66,15 +91,35 @@ def main(root, tag, steps, title=None):
         assert steps, "no step count in stats.log: give it on the command line"
     steps = float(steps)
     stats_csv = glob.glob(f"{root}/stats/**/*_kernel_stats.csv", recursive=True)[0]
-    shutil.copy(stats_csv, f"{prof}/{tag}_kernel_stats.csv")
-    rows = list(csv.DictReader(open(stats_csv)))
     agg = defaultdict(lambda: [0.0, 0])
-    for r in rows:
-        k = short(r["Name"]) or "other"
-        agg[k][0] += float(r["TotalDurationNs"])
-        agg[k][1] += int(r["Calls"])
+    cut = None
+    if last:
+        trace = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"])
+                        for r in csv.DictReader(open(glob.glob(f"{root}/stats/**/*_kernel_trace.csv", recursive=True)[0]))))
+        cut = _last_steps([t[2] for t in trace], last)
+    if cut:
+        byname = defaultdict(lambda: [0, 0.0])
+        for s0, e0, n in trace[cut[0]:cut[1]]:
+            byname[n][0] += 1
+            byname[n][1] += e0 - s0
+            k = short(n) or "other"
+            agg[k][0] += e0 - s0
+            agg[k][1] += 1
+        with open(f"{prof}/{tag}_kernel_stats.csv", "w", newline="") as fh:     # the same columns as rocprofv3's own summary
+            wr = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+            wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+            total = sum(v[1] for v in byname.values())
+            for n, (c, ns) in sorted(byname.items(), key=lambda kv: -kv[1][1]):
+                wr.writerow([n, c, int(ns), round(ns / c, 1), round(100.0 * ns / total, 3)])
+        steps = float(last)
+    else:
+        shutil.copy(stats_csv, f"{prof}/{tag}_kernel_stats.csv")
+        for r in csv.DictReader(open(stats_csv)):
+            k = short(r["Name"]) or "other"
+            agg[k][0] += float(r["TotalDurationNs"])
+            agg[k][1] += int(r["Calls"])
     counters = ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
-    S = {c: counter_pass(root, c) for c in counters}
+    S = {c: counter_pass(root, c, last if cut else None) for c in counters}
     pm = {"source": "rocprofv3 --kernel-trace --stats (times) and rocprofv3 --pmc <counter> --kernel-trace, ONE counter per pass, all passes "
                     "with identical program arguments (tools/run/profile_config.sh); aggregated by tools/profile_summary.py",
           "unit": "traffic_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads, "
@@ -107,7 +152,8 @@ def main(root, tag, steps, title=None):
     tot = sum(v[0] for v in agg.values()) / steps / 1e6
     launches = sum(v[1] for v in agg.values()) / steps
     L = [f"# {title or tag} — rocprofv3\n",
-         f"Kernel-trace pass: {launches:.0f} launches and {tot:.2f} ms of kernel time per step / tick ({steps:.0f} traced; `{tag}_kernel_stats.csv`). "
+         f"Kernel-trace pass: {launches:.0f} launches and {tot:.2f} ms of kernel time per step / tick ({steps:.0f} "
+         f"{'timed steps = the last ones of the process' if cut else 'traced'}; `{tag}_kernel_stats.csv`). "
          f"Counter passes: one counter each, same arguments (`{tag}_pmc_traffic.json`).\n",
          "| kernel | launches / step | ms / step | avg us | % of kernel time | HBM-side traffic / launch | MFMA busy | HBM-side rate |",
          "|---|---|---|---|---|---|---|---|"]
@@ -122,4 +168,4 @@ def main(root, tag, steps, title=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
