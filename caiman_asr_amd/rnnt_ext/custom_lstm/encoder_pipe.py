@@ -19,8 +19,7 @@ import torch
 
 from caiman_asr_amd import _lib
 from caiman_asr_amd.rnnt_ext.cuda.lstm import _step_bytes
-from caiman_asr_amd.rnnt_ext.custom_lstm import stack
-from caiman_asr_amd.rnnt_ext.custom_lstm.stack import INTERLEAVED, RINGS_ZEROED, _pad32, _perm_rows, _Scratch, _unperm_rows
+from caiman_asr_amd.rnnt_ext.custom_lstm.stack import INTERLEAVED, RINGS_ZEROED, _pad32, _Scratch, _unperm_rows
 
 # timesteps per pipeline chunk: 0 = by hidden size (`_chunk`); CAIMAN_ENC_PIPE_CHUNK forces a value
 CH = int(__import__("os").environ.get("CAIMAN_ENC_PIPE_CHUNK", "0"))

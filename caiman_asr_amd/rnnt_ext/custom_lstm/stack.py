@@ -15,7 +15,6 @@ pass is the mirror image (top layer first, time reversed); weight gradients are 
 Numerics are those of the per-layer path (same kernels, same GEMM operands); only the schedule differs.
 """
 import ctypes
-from typing import List, Optional
 
 import torch
 

@@ -13,7 +13,6 @@ def short(name):
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"at::native::", "", name)
-    m = re.match(r"(_ZN6caiman\w*?\d+)(\w+?kernel)", name)
     return name[:70]
 
 
