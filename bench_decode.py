@@ -288,7 +288,8 @@ def main():
             last = dec.close()
             tokens += dec.search.count_final_tokens(last[0], len(last[1]))
     lat.sort()
-    p50, p99, worst = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.99 * len(lat)))], lat[-1]
+    # nearest-rank percentiles: the 99th of 100 ticks is the second-worst one (int(0.99 n) indexed the worst: the maximum)
+    p50, p99, worst = lat[len(lat) // 2], lat[max(0, -(-99 * len(lat) // 100) - 1)], lat[-1]
     if args.decoder == "beam" and args.profile_host:
         print("[host profile, ms per tick]", {k: round(v * 1e3 / args.ticks, 3) if k not in ("rounds", "expansions")
                                               else v / args.ticks for k, v in dec.dec.profile.items()}, file=sys.stderr)
