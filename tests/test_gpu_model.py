@@ -485,3 +485,51 @@ def test_embedding_gradient_kernel_equals_autograd(dtype):
     for trial in range(2):
         (overlap.embedding(emb, idx).to(dtype) * w).float().sum().backward()
     assert torch.equal(emb.weight.grad, got)
+
+
+def test_embedding_gradient_kernel_wide_rows_and_foreign_tokens():
+    """Rows wider than one pass of the kernel's column registers (E > 2048: two passes over the token list), a token id
+    outside the table (ignored, as nothing may be written for it) and a single position."""
+    import ctypes  # noqa: F401
+
+    from caiman_asr_amd import _lib
+
+    V, E = 40, 2100
+    g = torch.Generator().manual_seed(9)
+    tokens = torch.randint(0, V, (300,), generator=g)
+    tokens[17], tokens[250] = V + 5, -3
+    dy = torch.randn(300, E, generator=g)
+    grad = torch.randn(V, E, generator=g)
+    ref = grad.clone().double()
+    for n in range(300):
+        if 0 <= int(tokens[n]) < V:
+            ref[int(tokens[n])] += dy[n].double()
+    td, dd, gd = tokens.to(DEV), dy.to(DEV), grad.to(DEV)
+    lib = _lib.lib()
+    _lib.check(lib.caiman_embedding_grad(_lib.ptr(td), 300, _lib.ptr(dd), _lib.dtype_tag(torch.float32), V, E, _lib.ptr(gd),
+                                         _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(gd.cpu().double(), ref, rtol=0, atol=1e-4)
+    one = torch.zeros(V, E, device=DEV)
+    _lib.check(lib.caiman_embedding_grad(_lib.ptr(td[3:4]), 1, _lib.ptr(dd[3:4]), _lib.dtype_tag(torch.float32), V, E, _lib.ptr(one),
+                                         _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(one[int(tokens[3])], dd[3]) and float(one.abs().sum()) == float(dd[3].abs().sum())
+
+
+def test_slab_accumulate_adds_the_slabs_in_order():
+    """caiman_slab_accumulate: dst += slab 0 + slab 1 + ... (fp32, fixed order): against the same sum in torch, bit for bit."""
+    from caiman_asr_amd import _lib
+
+    g = torch.Generator().manual_seed(4)
+    slabs = torch.randn(5, 3, 1028, generator=g).to(DEV)          # n = 3084 floats per slab: not a multiple of the block size
+    dst = torch.randn(3, 1028, generator=g).to(DEV)
+    ref = slabs[0].clone()
+    for s_ in range(1, 5):
+        ref = ref + slabs[s_]
+    ref = dst + ref
+    _lib.check(_lib.lib().caiman_slab_accumulate(_lib.ptr(slabs), 5, slabs[0].numel(), _lib.ptr(dst), _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, ref)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.lib().caiman_slab_accumulate(_lib.ptr(slabs), 5, 3083, _lib.ptr(dst), _lib.stream()))
