@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from caiman_asr_amd.rnnt.joint import TransducerJoint
 from caiman_asr_amd.rnnt.rnn import rnn
-from caiman_asr_amd.rnnt.state import (BatchChunks, EncoderState, PredNetState, RNNTState, get_pred_net_state,
+from caiman_asr_amd.rnnt.state import (EncoderState, PredNetState, RNNTState, get_pred_net_state,
                                        maybe_get_last_nonpadded)
 
 
@@ -183,26 +183,11 @@ class RNNT(nn.Module):
                     and p.pipeline_layers and a.num_layers + b.num_layers + p.num_layers <= 8
                     and pred_in.shape[1] == x.shape[1]):
                 return None
-        B = x.shape[1]
-        bounds = self._resident_batch_chunks(B, a.hidden_size, a.num_layers + b.num_layers + (p.num_layers if p is not None else 0))
-        if bounds is None:
-            y, all_pre, all_post, yp, all_pred = ep.encoder_pipe(
-                x, a, b, f, enc_state.pre_rnn if enc_state else None, enc_state.post_rnn if enc_state else None,
-                pred=p, xp=pred_in, pred_state=pred_state)
-        else:
-            # 32 utterances at a time: utterances are independent, and for this hidden size the weight-resident kernels (one
-            # launch per pipeline tick instead of one per timestep and layer) exist only up to 32 rows
-            def rows(state, lo, hi):
-                return None if state is None else (state[0][:, lo:hi], state[1][:, lo:hi])
-
-            outs = [ep.encoder_pipe(x[:, lo:hi], a, b, f, rows(enc_state.pre_rnn if enc_state else None, lo, hi),
-                                    rows(enc_state.post_rnn if enc_state else None, lo, hi), pred=p,
-                                    xp=None if pred_in is None else pred_in[:, lo:hi], pred_state=rows(pred_state, lo, hi))
-                    for lo, hi in bounds]
-            y = torch.cat([o[0] for o in outs], dim=1)
-            all_pre, all_post = BatchChunks([o[1] for o in outs], bounds), BatchChunks([o[2] for o in outs], bounds)
-            yp = None if outs[0][3] is None else torch.cat([o[3] for o in outs], dim=1)
-            all_pred = None if outs[0][4] is None else BatchChunks([o[4] for o in outs], bounds)
+        # (batches the batch-tile LSTM kernels do not take -- B > 32 at H = 1536 / 768 -- are cut into 32-row slices inside the
+        # library's wave calls, csrc/lstm.hip::res_batch_slice: everything else of the pipeline runs at the full batch)
+        y, all_pre, all_post, yp, all_pred = ep.encoder_pipe(
+            x, a, b, f, enc_state.pre_rnn if enc_state else None, enc_state.post_rnn if enc_state else None,
+            pred=p, xp=pred_in, pred_state=pred_state)
         if post.dropout:
             y = post.dropout(y)
         return y, (x_lens.int() + f - 1) // f, all_pre, all_post, yp, all_pred
@@ -225,23 +210,6 @@ class RNNT(nn.Module):
         if all_pre is not None and all_post is not None:
             new_state = EncoderState(pre_rnn=pre_last, post_rnn=post_last)
         return x, x_lens, new_state
-
-    @staticmethod
-    def _resident_batch_chunks(B, hidden, n_layers):
-        """[(lo, hi), ...] in steps of 32 when the weight-resident LSTM kernels would not take a batch of B at this hidden
-        size but do take 32, else None.  The library now slices such batches itself (csrc/lstm.hip::res_batch_slice: the
-        B <= 32 kernels once per 32 rows, everything else of the step at the full batch), so this only applies with
-        CAIMAN_LSTM_BATCH_SLICES=0 (the round-4 A/B).  CAIMAN_BATCH_CHUNKS=0 turns the chunking off."""
-        import os
-
-        if B <= 32 or os.environ.get("CAIMAN_BATCH_CHUNKS", "1") == "0":
-            return None
-        from caiman_asr_amd import _lib
-
-        lib = _lib.lib()
-        if lib.caiman_lstm_resident_would_run(B, hidden, min(n_layers, 8)) or not lib.caiman_lstm_resident_would_run(32, hidden, min(n_layers, 8)):
-            return None
-        return [(lo, min(lo + 32, B)) for lo in range(0, B, 32)]
 
     def _joint_in(self, lin, x):
         """joint_enc / joint_pred (torch.nn.Linear in the reference, model.py:82-83 there): on the GPU in training the same

@@ -25,15 +25,6 @@ class RNNTState:
     pred_net_state: PredNetState
 
 
-class BatchChunks:
-    """All hidden states of an LSTM stack, kept as one (h, c) pair [L, T, b, H] per chunk of the batch (rnnt/model.py runs the
-    layer pipeline 32 utterances at a time where the weight-resident kernels only exist for up to 32): the selections below
-    gather from each chunk and concatenate the small results, instead of concatenating gigabytes of states first."""
-
-    def __init__(self, parts, bounds):
-        self.parts, self.bounds = list(parts), list(bounds)
-
-
 def _rows_selectable(t):
     """[L, T, B, H] with the rows of a step contiguous and 4-byte granular: what the gather kernel takes"""
     return (t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3]
@@ -44,9 +35,6 @@ def _rows_selectable(t):
 
 def get_last_nonpadded_states(all_hid, lens, how_far_back: int = 0):
     """all_hid: (h, c) each [L, T, B, H]; pick step lens[b]-1-how_far_back per utterance."""
-    if isinstance(all_hid, BatchChunks):
-        got = [get_last_nonpadded_states(part, lens[a:b], how_far_back) for part, (a, b) in zip(all_hid.parts, all_hid.bounds)]
-        return torch.cat([g[0] for g in got], dim=1), torch.cat([g[1] for g in got], dim=1)
     h, c = all_hid
     if h.is_cuda and _rows_selectable(h) and _rows_selectable(c) and h.shape == c.shape and h.dtype == c.dtype:
         # one launch for both tensors and every layer (include/caiman_rnnt.h caiman_lstm_last_states) instead of the

@@ -159,8 +159,8 @@ def test_base_85m_step_at_128_utterances_per_gpu_runs_on_the_batch_tile_kernels(
 def test_step_at_128_per_gpu_matches_the_bf16_storage_oracle(size, V):
     """("large": the same check on large-196M, BASELINE.json configs[3] at the reference's 128 utterances per GPU
     (docs/src/training/training_times.md:8): H = 1536 / 768 have weight-resident kernels for up to 32 rows only, so the
-    layer pipeline runs the batch in four chunks of 32 -- rnnt/model.py::_resident_batch_chunks -- and every launch of the
-    step must still be a resident one.)
+    library's wave calls run them on four 32-row slices of the batch -- csrc/lstm.hip::res_batch_slice -- and every launch
+    of the step must still be a resident one.)
     BASELINE.json configs[2] per-GPU shape against the ORACLE (not against another kernel of this library): base-85M,
     B = 128, T = 40 frames, one bf16 training step on the weight-resident batch-tile kernels vs oracle.model.loss_and_grads
     rounded where the HIP path stores 16-bit values (`storage=torch.bfloat16`): loss and four gradients, one per
