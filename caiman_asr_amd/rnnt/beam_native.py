@@ -231,6 +231,7 @@ class HipBeamStep:
         self.cap = 0
         self.stats = None
         self.graphs = {}     # (rows bucket, operand addresses) -> captured round (hipGraph): one launch instead of nine
+        self._graph_off = False
 
     def _weights(self, cd):
         w = self.w.get(cd)
@@ -298,7 +299,7 @@ class HipBeamStep:
         ih[0, :n], ih[1, :n], ih[2, :n] = y_last, state_in, state_out
         ih[3:5].reshape(-1).view(np.int64)[:n] = rows
         nb = n
-        if ROUND_GRAPH:
+        if ROUND_GRAPH and not self._graph_off:
             # the round as ONE graph launch, captured per bucket of row counts; the padding rows start from the zero state,
             # read encoder row 0 and write their state into the pools' spare last row
             nb = _rows_bucket(n)
@@ -317,15 +318,24 @@ class HipBeamStep:
                 self._round(frames2d, nb, w, cd)
                 torch.cuda.current_stream().synchronize()
                 b = 64
-                while b <= self.cap:
-                    if (b,) + env not in self.graphs:
-                        gb = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(gb, capture_error_mode="thread_local"):   # other threads (a data feed) may use the GPU meanwhile
-                            self._round(frames2d, b, w, cd)
-                        self.graphs[(b,) + env] = gb
-                    b = b * 2 if b < 512 else b + 256
-                g = self.graphs[(nb,) + env]
-            g.replay()
+                try:
+                    while b <= self.cap:
+                        if (b,) + env not in self.graphs:
+                            gb = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(gb, capture_error_mode="thread_local"):   # other threads (a data feed) may use the GPU meanwhile
+                                self._round(frames2d, b, w, cd)
+                            self.graphs[(b,) + env] = gb
+                        b = b * 2 if b < 512 else b + 256
+                except Exception as e:      # a capture the runtime refuses: the same kernels as eager launches, said once
+                    import warnings
+
+                    warnings.warn(f"beam round: graph capture failed ({e!r}); continuing with eager launches")
+                    self._graph_off = True
+                    self.graphs.clear()
+                    torch.cuda.synchronize()
+                g = self.graphs.get((nb,) + env)
+            if g is not None:
+                g.replay()         # (the eager warm-up above has already run this round when the capture failed)
         else:
             self._round(frames2d, n, w, cd)
         k = self.k
