@@ -334,10 +334,10 @@ def feed_beside_step(step, args, dev, first_index):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 30 = five passes over the six synthetic batches (0.75 s timed): the GPU boxes show a one-off ~20 ms stall in about one
+    # 60 = ten passes over the six synthetic batches (1.5 s timed): the GPU boxes show a one-off ~20 ms stall in about one
     # run out of three (any step, either tree in an A/B: `step_ms_device` in the JSON line shows it); over 12 steps that
-    # is +1.7 ms on the average, over 30 steps +0.7
-    ap.add_argument("--steps", type=int, default=30)
+    # is +1.7 ms on the average, over 60 steps +0.3
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--model", choices=["base", "large"], default="base",
