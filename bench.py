@@ -557,6 +557,9 @@ def main():
     step_ends = []                 # one event per step on the device clock: shows a single slow step inside the average
     issue_ms = []                  # host time to queue each step
     segs0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)   # hipMalloc calls of the caching allocator so far
+    loop_start = torch.cuda.Event(enable_timing=True)
+    loop_start.record(main_stream if args.main_priority != 0 else torch.cuda.current_stream())
+    step_ends.append(loop_start)   # so that the first timed step has a predecessor too
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -579,6 +582,11 @@ def main():
             torch.cuda.synchronize()
             log(f"step {i}: launch {1e3 * (tl - ts):.1f} ms, total {1e3 * (time.perf_counter() - ts):.1f} ms, "
                 f"audio {a:.0f} s, cells {c}")
+    # the host polls the last step's event before the closing barrier + synchronize: a thread that sleeps in a blocking
+    # synchronise is woken up to several ms late on some boxes (runs whose every step was normal on the device clock came out
+    # 0.4-0.6 ms per step slower over 12 steps), and that is the host's wake-up latency, not the step
+    while in_flight and not in_flight[-1].query():
+        pass
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.timing.enabled = False
@@ -622,7 +630,7 @@ def main():
         # waits `wait_for_device` ms per step for the device to catch up (run-ahead limit of two steps)
         out["host_ms_per_step"] = {"issue": round(host_issue / args.steps * 1e3, 2),
                                    "wait_for_device": round(host_wait / args.steps * 1e3, 2)}
-        # device-clock time between the ends of consecutive steps (the first timed step has no predecessor event)
+        # device-clock time of every timed step: between the ends of consecutive steps (the first: from the start of the loop)
         out["host_issue_ms"] = issue_ms
         out["allocator_segments_added_in_timed_loop"] = int(torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - segs0)
         out["step_ms_device"] = [round(step_ends[j - 1].elapsed_time(step_ends[j]), 2) for j in range(1, len(step_ends))]
